@@ -1,0 +1,182 @@
+"""Pins oracle/council_oracle.py against outputs of the REAL reference (tests/golden/*.npz).
+
+The fixtures were produced by oracle/make_golden.py running /root/reference through the import
+shim.  Same ATen CPU kernels on both sides, so the match is expected to the last few ulps; the
+tolerance (1e-5 relative) only absorbs thread-count dependent reduction order in oneDNN."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import council_oracle as O
+from golden_util import Golden, case_names, rel_err, summary
+
+TOL = 1e-5
+CASES = case_names()
+
+
+def test_fixtures_present():
+    assert len(CASES) >= 6
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_probe_forward(name):
+    g = Golden(name)
+    st = g.init_state()
+    s = torch.from_numpy(g["probe/style"])
+    x = {"a2b": torch.from_numpy(g["x_a"]), "b2a": torch.from_numpy(g["x_b"])}
+    for d in g.dirs:
+        sd = {k: torch.from_numpy(v) for k, v in st[d]["gen"][0].items()}
+        gen = O.OracleGen(sd, g.cfg["gen"])
+        c, s_fake = gen.encode(x[d])
+        img, mask = gen.decode(c, s, x[d], return_mask=True)
+        assert rel_err(c.numpy(), g["probe/%s/content" % d]) < TOL
+        assert rel_err(s_fake.numpy(), g["probe/%s/style_fake" % d]) < TOL
+        assert rel_err(img.numpy(), g["probe/%s/image" % d]) < TOL
+        assert rel_err(mask.numpy(), g["probe/%s/mask" % d]) < TOL
+        dis = O.OracleDis({k: torch.from_numpy(v) for k, v in st[d]["dis"][0].items()}, g.cfg["dis"])
+        for sc, o in enumerate(dis.forward(img)):
+            assert rel_err(o.numpy(), g["probe/%s/dis_out%d" % (d, sc)]) < TOL
+        if "dis_council" in g.nets:
+            dc = O.OracleDisCouncil({k: torch.from_numpy(v) for k, v in st[d]["dis_council"][0].items()}, g.cfg["dis"])
+            for sc, o in enumerate(dc.forward(img, x[d])):
+                assert rel_err(o.numpy(), g["probe/%s/disc_out%d" % (d, sc)]) < TOL
+
+
+def _grads(sd):
+    return {k: t.grad.numpy() for k, t in sd.items() if t.requires_grad and t.grad is not None}
+
+
+def _weights(sd):
+    return {k: t.detach().numpy() for k, t in sd.items() if "running_" not in k}
+
+
+def _check_net(g, tr, pre, d, net, i, it):
+    # iteration 1 starts from weights that already differ in the last ulp (Adam on round-off-level
+    # gradients) and the generator amplifies that (steep mask head): 10x looser there
+    TOL = 1e-5 if it == 0 else 1e-4
+    if it > 0 and net == 'gen':
+        TOL = 5e-3      # generator grads carry 2-4e-3 intrinsic fp32 noise
+    sd = tr.sd[d][net][i]
+    gs, ws = _grads(sd), _weights(sd)
+    ref_gs = g[pre + "gradsum/%s/%d" % (d, i)]
+    assert summary(gs).shape == ref_gs.shape, "set of tensors that received a gradient differs"
+    # column 1 (l2 norm) and 2 (abs max) are stable; the plain sum cancels, compare it against the norm
+    got = summary(gs)
+    # conv biases that feed an instance norm have a mathematically zero gradient (1e-11 noise in
+    # the reference): tolerances are relative to the network's gradient scale, not per tensor
+    scale = ref_gs[:, 1].max()
+    assert np.all(np.abs(got[:, 1] - ref_gs[:, 1]) <= TOL * ref_gs[:, 1] + 1e-6 * scale)
+    assert np.all(np.abs(got[:, 0] - ref_gs[:, 0]) <= 10 * TOL * ref_gs[:, 1] + 1e-5 * scale)
+    ref_ws = g[pre + "postsum/%s/%d" % (d, i)]
+    gotw = summary(ws)
+    # tensors whose gradient is pure round-off noise take Adam-normalised random steps (|step| <= lr
+    # per iteration, g/(|g|+eps) with |g| ~ eps): excluded from the post-step comparison
+    gkeys, wkeys = sorted(gs), sorted(ws)
+    noisy = {k for k, r in zip(gkeys, ref_gs) if r[1] < 1e-6 * scale}
+    live = np.array([k not in noisy and k in gs for k in wkeys])
+    assert np.all((np.abs(gotw[:, 1] - ref_ws[:, 1]) <= TOL * ref_ws[:, 1] + 1e-7)[live])
+    full = g.sub(pre + "grad/%s/%d/" % (d, i))
+    gmax = max([np.abs(v).max() for v in full.values()] + [1e-30])
+    for k, v in full.items():
+        assert np.abs(gs[k] - v).max() <= TOL * np.abs(v).max() + 1e-6 * gmax, (pre, d, net, i, k)
+    fullw = g.sub(pre + "post/%s/%d/" % (d, i))
+    for k, v in fullw.items():
+        if k not in noisy:
+            assert np.abs(ws[k] - v).max() < 1e-6, (pre, d, net, i, k)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_two_iterations(name):
+    g = Golden(name)
+    cfg = g.cfg
+    random.seed(1); np.random.seed(1); torch.manual_seed(12345)
+    tr = O.OracleTrainer(cfg, g.init_state())
+    x_a, x_b = torch.from_numpy(g["x_a"]), torch.from_numpy(g["x_b"])
+    base_it = cfg["iteration"]
+    # replay the reference's host RNG: style noise comes from the fixture (R1), colleague picks too
+    for it in range(2):
+        cfg["iteration"] = base_it + it
+        pre = "it%d/" % it
+        noise = list(g[pre + "dis/randn"])
+        _patch_randn(noise)
+        tr.dis_update(x_a, x_b, cfg)
+        assert not noise, "dis_update drew fewer style tensors than the reference"
+        np.testing.assert_allclose([float(v) for v in tr.loss_dis_total], g[pre + "dis/loss_total"], rtol=TOL)
+        for d in g.dirs:
+            for i in range(g.C):
+                _check_net(g, tr, pre + "dis/", d, "dis", i, it)
+        if "dis_council" in g.nets:
+            ran_ref = bool(g[pre + "disc/ran"])
+            noise = list(g[pre + "disc/randn"]) if ran_ref else []
+            picks = list(g[pre + "disc/choice"]) if ran_ref else []
+            _patch_randn(noise); _patch_choice(picks)
+            ran = tr.dis_council_update(x_a, x_b, cfg)
+            assert bool(ran) == ran_ref
+            if ran_ref:
+                assert not noise and not picks
+                np.testing.assert_allclose([float(v) for v in tr.loss_disc_total], g[pre + "disc/loss_total"], rtol=TOL)
+                for d in g.dirs:
+                    for i in range(g.C):
+                        _check_net(g, tr, pre + "disc/", d, "dis_council", i, it)
+        noise = list(g[pre + "gen/randn"])
+        _patch_randn(noise)
+        tr.gen_update(x_a, x_b, cfg, cfg["iteration"])
+        assert not noise
+        np.testing.assert_allclose([float(v) for v in tr.loss_gen_total], g[pre + "gen/loss_total"], rtol=TOL)
+        for d in g.dirs:
+            np.testing.assert_allclose([float(v) for v in tr.loss_gen_adv[d]], g[pre + "gen/loss_adv_%s" % d], rtol=TOL)
+            np.testing.assert_allclose([float(v) for v in tr.council_loss[d]], g[pre + "gen/council_loss_%s" % d], rtol=TOL)
+            for nm, got in (("mask_zero_one", tr.loss_mask_zero_one), ("mask_total", tr.loss_mask_total),
+                            ("mask_tv", tr.loss_mask_tv)):
+                ref = g[pre + "gen/%s_%s" % (nm, d)]
+                if len(ref):
+                    np.testing.assert_allclose([float(v) for v in got[d]], ref, rtol=TOL, atol=1e-9)
+            for i in range(g.C):
+                _check_net(g, tr, pre + "gen/", d, "gen", i, it)
+    _unpatch()
+
+
+def test_host_rng_contract():
+    """R1: with the reference's seeds the oracle draws the same noise / picks without any patching."""
+    g = Golden("m2f_c3")
+    cfg = g.cfg
+    tr = O.OracleTrainer(cfg, g.init_state())
+    # the reference trainer ctor consumed RNG before the first update, so only Python's `random`
+    # (untouched by the ctor) can be compared from a fresh seed: picks of iteration 0
+    random.seed(1)
+    x_a, x_b = torch.from_numpy(g["x_a"]), torch.from_numpy(g["x_b"])
+    tr.dis_council_update(x_a, x_b, cfg)
+    flat = [j for p in tr.council_picks for j in p]
+    assert flat == list(g["it0/disc/choice"])
+
+
+# ---- host-RNG replay helpers -----------------------------------------------------------
+_orig_randn, _orig_choice = torch.randn, random.choice
+
+
+def _patch_randn(queue):
+    def randn(*shape, **k):
+        t = torch.from_numpy(np.array(queue.pop(0)))
+        assert tuple(t.shape) == tuple(shape if not isinstance(shape[0], (tuple, list)) else shape[0])
+        return t
+    torch.randn = randn
+
+
+def _patch_choice(queue):
+    def choice(seq):
+        c = int(queue.pop(0))
+        assert c in seq
+        return c
+    random.choice = choice
+
+
+def _unpatch():
+    torch.randn, random.choice = _orig_randn, _orig_choice
+
+
+@pytest.fixture(autouse=True)
+def _restore_rng_functions():
+    yield
+    _unpatch()
