@@ -1,0 +1,201 @@
+"""bench.py -- Council-GAN training images/sec on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one train.py:237-251 iteration: dis_update + dis_council_update + gen_update over all
+council members, all Adam steps included, inputs already resident in HBM, nothing skipped.
+Workload at N=1: BASELINE.json configs[2] -- male2female, 256x256, council=4, batch=4 (the
+configuration the metric is quoted on).  N=2,4: same problem, members sharded (strong scaling).
+N=8: council=8 (configs[4]), one member per GPU.  images/sec = batch * steps / wall-seconds, wall =
+max over ranks between barrier+synchronize brackets.
+
+Rank 0 prints ONE JSON line; at N=1 it also carries
+  "roofline":     dominant kernel (fp32-MFMA implicit-GEMM conv) algorithmic TFLOP/s from HIP events
+                  on the launch stream vs the 157.3 TFLOP/s fp32 matrix peak, plus the whole-step figure
+                  (W_min of SURVEY.md 8d / step time);
+  "cpu_baseline": the oracle (CPU restatement of the reference) timed on this box's host cores on a
+                  bounded sample of the same workload.
+"""
+import argparse
+import copy
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import yaml  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+
+# per-forward GFLOP at sigma = B*(H/128)^2 = 1 (hooks on every Conv2d/Linear)
+_S, _A, _D, _P, _Q, _c1, _p1, _q1 = 3.127, 14.535, 19.621, 1.038, 4.336, 0.308, 0.031, 0.142
+
+
+def w_min_tflop(batch, size, council, n_rel):
+    """De-duplicated algorithmic work per iteration (the figure the roofline uses)."""
+    sigma = batch * (size / 128.0) ** 2
+    if council >= 2:
+        k = min(n_rel, council)
+        kp = min(k, council - 1)
+        per = (3 * _A - _c1 + 6 * _D) + (8 * _P - 2 * _p1) + ((1 + kp) * (3 * _Q - _q1) + 2 * _Q)
+    else:
+        per = (3 * _A - _c1 + 4 * _D) + (8 * _P - 2 * _p1)
+    return per * sigma * council / 1000.0
+
+
+def build_config(args, world):
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", args.config)))
+    council = args.council if args.council else max(4, world)
+    cfg['council']['council_size'] = council
+    cfg['batch_size'] = args.batch
+    cfg['new_size'] = cfg['crop_image_height'] = cfg['crop_image_width'] = args.size
+    cfg['iteration'] = 60000          # council (>= 10 000) and focus (> 50 000) terms live, SURVEY.md 8d
+    return cfg
+
+
+def cpu_baseline(cfg, tr_state_fn, size, seconds_hint=25.0):
+    """Oracle ("port" of the reference) on the host cores, bounded sample: ONE iteration of the same
+    council / resolution at batch_size 1."""
+    from oracle import council_oracle as O
+    cfg = copy.deepcopy(cfg)
+    cfg['batch_size'] = 1
+    otr = O.OracleTrainer(cfg, tr_state_fn())
+    x_a, x_b = O.synthetic_batch(1, size)
+    O.seed_all(1)
+    t0 = time.time()
+    otr.dis_update(x_a, x_b, cfg)
+    otr.dis_council_update(x_a, x_b, cfg)
+    otr.gen_update(x_a, x_b, cfg, cfg['iteration'])
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/council_oracle.py, 1 cold iteration (dis+dis_council+gen updates, all %d members) of the "
+                      "same %dx%d council=%d workload at batch_size 1 instead of %d; %.1f s of CPU work, %d torch threads"
+                      % (cfg['council']['council_size'], size, size, cfg['council']['council_size'], 0, dt,
+                         torch.get_num_threads())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="male2female_council_folder.yaml")
+    ap.add_argument("--council", type=int, default=0, help="override council size (default max(4, gpus))")
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    args = ap.parse_args()
+
+    import council_gan_amd as cga
+    rank, world, local_rank = cga.init_distributed("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if world != max(args.gpus, 1) and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    cfg = build_config(args, world)
+    council = cfg['council']['council_size']
+    from oracle import council_oracle as O      # only synthetic_batch / seed_all helpers + the cpu_baseline leg
+    O.seed_all(cfg['random_seed'])              # train.py:55-62 -- identical on every rank
+    trainer = cga.Council_Trainer(cfg, str(device))
+    state_fn = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        host_state = {d: {'gen': [O.to_numpy_state(m.state_dict()) for m in trainer._nets('gen', d)],
+                          'dis': [O.to_numpy_state(m.state_dict()) for m in trainer._nets('dis', d)],
+                          'dis_council': [O.to_numpy_state(m.state_dict()) for m in trainer._nets('disc', d)]}
+                      for d in trainer._dirs}
+        state_fn = lambda: host_state
+    trainer.cuda(device)
+    x_a, x_b = O.synthetic_batch(args.batch, args.size)
+    x_a, x_b = x_a.to(device), x_b.to(device)      # inputs resident in HBM before the timed region
+
+    def step(it):
+        cfg['iteration'] = 60000 + it
+        trainer.dis_update(x_a, x_b, cfg)
+        trainer.dis_council_update(x_a, x_b, cfg)
+        trainer.gen_update(x_a, x_b, cfg, cfg['iteration'])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        step(it)
+    fence()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        step(args.warmup + it)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = 1000.0 * elapsed / args.steps
+    value = args.batch * args.steps / elapsed
+    n_rel = cfg['council']['numberOfCouncil_dis_relative_iteration']
+    wmin = w_min_tflop(args.batch, args.size, council, n_rel)
+    out = {
+        "metric": "training images/sec (gen+dis step), 256x256 council=4, 1/2/4/8 MI355X",
+        "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "strong" if council == 4 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s %dx%d council=%d batch=%d: dis_update + dis_council_update + gen_update "
+                               "(train.py:237-251), fp32, all Adam steps" % (args.config.split('_')[0], args.size,
+                                                                               args.size, council, args.batch),
+                   "members_per_gpu": council // world, "member_images_per_sec": round(value * council, 3),
+                   "algorithmic_tflop_per_step": round(wmin, 3)},
+    }
+
+    if rank == 0 and world == 1:
+        step_tflops = wmin / (ms_per_step / 1000.0)
+        roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "step_achieved": round(step_tflops, 2), "step_frac": round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4)}
+        if not args.no_kernel_profile:
+            # one more iteration with HIP events around every MFMA conv launch (on the launch stream)
+            cga.hip.prof_enable(True)
+            step(args.warmup + args.steps)
+            torch.cuda.synchronize()
+            prof = cga.hip.prof_collect()
+            cga.hip.prof_enable(False)
+            kernels = {k: {"launches": c, "avg_us": round(1000.0 * ms / c, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                           "share_of_conv_time": 0.0} for k, (c, ms, fl) in prof.items()}
+            tot_ms = sum(ms for _, ms, _ in prof.values())
+            tot_fl = sum(fl for _, _, fl in prof.values())
+            for k, (c, ms, fl) in prof.items():
+                kernels[k]["share_of_conv_time"] = round(ms / tot_ms, 4)
+            dom = max(prof.items(), key=lambda kv: kv[1][1])
+            dname, (dc, dms, dfl) = dom
+            ach = dfl / (dms * 1e-3) / 1e12
+            roof.update({"kernel": dname, "achieved": round(ach, 2), "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "avg_launch_us": round(1000.0 * dms / dc, 2), "launches_per_step": dc,
+                         "all_conv_kernels_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                         "conv_ms_per_step": round(tot_ms, 2), "executed_conv_tflop_per_step": round(tot_fl / 1e12, 3),
+                         "kernels": kernels})
+        else:
+            roof.update({"achieved": round(step_tflops, 2), "frac": round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4)})
+        out["roofline"] = roof
+        if state_fn is not None:
+            cb = cpu_baseline(cfg, state_fn, args.size)
+            cb["sample"] = cb["sample"].replace("instead of 0", "instead of %d" % args.batch)
+            out["cpu_baseline"] = cb
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

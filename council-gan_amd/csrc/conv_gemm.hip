@@ -1,0 +1,750 @@
+// Implicit-GEMM convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// Replaces nn.Conv2d-after-ZeroPad2d (reference networks.py:513,515-516), the bare 1x1 convs
+// (:44,142-143,348) and nn.Linear (:531, as a 1x1 conv on an Nx1x1xC tensor): forward,
+// data-gradient (same kernel, transposed weights + a different tap table) and weight-gradient.
+//
+// fp32 MFMA is the only datapath that meets the 1e-3 parity target; it is
+// bit-for-bit an fmaf chain.  One MFMA = 32x32x2, 64 cycles per SIMD, so the matrix pipe is
+// 16x slower than bf16 and LDS/global feeding is cheap in comparison: a 128x128 block tile with
+// BK = 32, register-staged prefetch of the next K-slice and ds_read_b128 operand fetches keeps
+// the pipe busy.
+//
+// GEMM view (forward / dgrad):  D[m][j] = sum_k A[m][k] * Wp[j][k]
+//   m = (n, oy, ox) output position, j = output channel, k = (tap, c) with c fastest.
+//   A is gathered on the fly from NHWC activations (zero padding, optional nearest-2x upsample,
+//   optional two-source channel concat); Wp is [Cout][T][Ct], k-contiguous.
+// GEMM view (wgrad):  dW[j][k] = sum_m dz[m][j] * A[m][k]   (split over m, deterministic reduce)
+#include <stddef.h>
+#include <mutex>
+#include <vector>
+#include "cg_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;       // K-slice per LDS stage
+constexpr int LDK = BK + 4;  // 36-float rows: 16-B aligned, conflict-free for ds_read_b128 (16 rows x 4 banks)
+
+struct RowInfo {
+    int base;     // n*H*W (pixel index of the sample), -1 = row beyond M
+    int ly0;      // oy*stride
+    int lx0;      // ox*stride
+    int out_off;  // element offset of the output pixel (forward) / of the dz row (wgrad)
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8).  Give each XCD a
+    // contiguous chunk of tile indices so the n-tiles of one m-tile (same gathered activations)
+    // share an L2.  Bijective for any nwg.  Speed only -- never correctness.
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + (bid >> 3);
+}
+
+// The geometry struct is the FIRST kernel argument: read its tap table with a per-lane index straight
+// from the kernarg segment (constant address space).  Indexing the by-value struct dynamically
+// would make the compiler spill it to scratch.
+__device__ __forceinline__ int load_tap(int t) {
+    const int8_t* ka = (const int8_t*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int dy = ka[offsetof(cg_conv_geom, dy) + t];
+    const int dx = ka[offsetof(cg_conv_geom, dx) + t];
+    return (dy & 0xffff) | (dx << 16);
+}
+
+__device__ __forceinline__ RowInfo decode_row(const cg_conv_geom& g, int m, int M, bool fwd_out) {
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int hw = g.Ho * g.Wo;
+    const int n = mm / hw;
+    const int rem = mm - n * hw;
+    const int oy = rem / g.Wo;
+    const int ox = rem - oy * g.Wo;
+    RowInfo ri;
+    ri.base = ok ? n * g.H * g.W : -1;
+    ri.ly0 = oy * g.stride;
+    ri.lx0 = ox * g.stride;
+    ri.out_off = fwd_out ? ((n * g.HoF + oy * g.osy + g.ooy) * g.WoF + ox * g.osx + g.oox) * g.Cout : mm * g.Cout;
+    return ri;
+}
+
+// one gathered input element / float4 (zero outside the image = ZeroPad2d)
+__device__ __forceinline__ bool tap_pixel(const cg_conv_geom& g, const RowInfo& ri, int tap_dydx, int& pix) {
+    int dy = (int)(short)(tap_dydx & 0xffff);
+    int dx = tap_dydx >> 16;
+    int ly = ri.ly0 + dy, lx = ri.lx0 + dx;
+    bool ok = ri.base >= 0 && ly >= 0 && lx >= 0 && ly < (g.H << g.up) && lx < (g.W << g.up);
+    pix = ri.base + (ly >> g.up) * g.W + (lx >> g.up);
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / data-gradient kernel
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool FAST>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(cg_conv_geom g, const float* __restrict__ x1,
+                                                       const float* __restrict__ x2,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       int M, int K, int tiles_n) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+    __shared__ RowInfo rows[BM];
+    __shared__ int taps[CG_MAX_TAPS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+    const int Ct = g.C1 + g.C2;
+
+    if (tid < g.T) taps[tid] = load_tap(tid);
+    for (int r = tid; r < BM; r += 256) {
+        rows[r] = decode_row(g, m0 + r, M, true);
+    }
+    __syncthreads();
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging registers
+    constexpr int A_V4 = BM / 32, B_V4 = BN / 32;  // FAST: float4 per thread
+    constexpr int A_S = BM / 8, B_S = BN / 8;      // generic: scalars per thread
+    float4 av[FAST ? A_V4 : 1], bv[FAST ? B_V4 : 1];
+    float as[FAST ? 1 : A_S], bs[FAST ? 1 : B_S];
+
+    const int nk = (K + BK - 1) / BK;
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        if constexpr (FAST) {
+            const int kc = tid & 7, r0 = tid >> 3;
+            const int tap = k0 / Ct;
+            const int c0 = k0 - tap * Ct + kc * 4;
+            const int td = taps[tap];
+#pragma unroll
+            for (int i = 0; i < A_V4; ++i) {
+                const RowInfo ri = rows[r0 + 32 * i];
+                int pix;
+                bool ok = tap_pixel(g, ri, td, pix);
+                av[i] = ok ? *reinterpret_cast<const float4*>(x1 + (size_t)pix * g.C1 + c0)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < B_V4; ++i) {
+                const int j = n0 + r0 + 32 * i;
+                bv[i] = j < g.Cout ? *reinterpret_cast<const float4*>(w + (size_t)j * K + k0 + kc * 4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int kk = tid & 31, rg = tid >> 5;
+            const int k = k0 + kk;
+            const bool kv = k < K;
+            const int tap = kv ? k / Ct : 0;
+            const int c = k - tap * Ct;
+            const int td = taps[tap];
+            const bool second = c >= g.C1;
+            const float* src = second ? x2 : x1;
+            const int cs = second ? g.C2 : g.C1;
+            const int cc = second ? c - g.C1 : c;
+#pragma unroll
+            for (int i = 0; i < A_S; ++i) {
+                const RowInfo ri = rows[rg + 8 * i];
+                int pix;
+                bool ok = tap_pixel(g, ri, td, pix) && kv;
+                as[i] = ok ? src[(size_t)pix * cs + cc] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < B_S; ++i) {
+                const int j = n0 + rg + 8 * i;
+                bs[i] = (kv && j < g.Cout) ? w[(size_t)j * K + k] : 0.f;
+            }
+        }
+    };
+
+    auto store_tile = [&]() {
+        if constexpr (FAST) {
+            const int kc = tid & 7, r0 = tid >> 3;
+#pragma unroll
+            for (int i = 0; i < A_V4; ++i)
+                *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDK + kc * 4]) = av[i];
+#pragma unroll
+            for (int i = 0; i < B_V4; ++i)
+                *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDK + kc * 4]) = bv[i];
+        } else {
+            const int kk = tid & 31, rg = tid >> 5;
+#pragma unroll
+            for (int i = 0; i < A_S; ++i) As[(rg + 8 * i) * LDK + kk] = as[i];
+#pragma unroll
+            for (int i = 0; i < B_S; ++i) Bs[(rg + 8 * i) * LDK + kk] = bs[i];
+        }
+    };
+
+    const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight under the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const float4*>(&As[(wm0 + i * 32 + l31) * LDK + ks * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const float4*>(&Bs[(wn0 + j * 32 + l31) * LDK + ks * 8 + lh * 4]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // lane (l31, lh) feeds A[row l31][k], B[k][col l31] with the SAME k = ks*8 + lh*4 + e
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + j * 32 + l31;
+        if (col >= g.Cout) continue;
+        const float bj = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const RowInfo ri = rows[row];
+                if (ri.base >= 0) y[(size_t)ri.out_off + col] = cg_apply_act(acc[i][j][r] + bj, g.act);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight-gradient kernel:  part[split][co][k] = sum_{m in split} dz[m][co] * A[m][k]
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool FAST>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const float* __restrict__ x1,
+                                                         const float* __restrict__ x2,
+                                                         const float* __restrict__ dz, float* __restrict__ out,
+                                                         int M, int K, int tiles_n, int slices_per_split) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int BP = 32;  // output positions per stage
+    __shared__ __attribute__((aligned(16))) float Ds[BP * BM];
+    __shared__ __attribute__((aligned(16))) float Xs[BP * BN];
+    __shared__ RowInfo rows[2][BP];
+    __shared__ int taps[CG_MAX_TAPS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int tile = blockIdx.x;
+    const int co0 = (tile / tiles_n) * BM;
+    const int j0 = (tile % tiles_n) * BN;
+    const int Ct = g.C1 + g.C2;
+    const int split = blockIdx.z;
+    const int nslices_total = (M + BP - 1) / BP;
+    const int s_begin = split * slices_per_split;
+    const int s_end = min(s_begin + slices_per_split, nslices_total);
+
+    if (tid < g.T) taps[tid] = load_tap(tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int D_V4 = (BP * BM / 4) / 256;  // float4 per thread for the dz tile
+    constexpr int X_V4 = (BP * BN / 4) / 256;
+    constexpr int D_S = BP * BM / 256, X_S = BP * BN / 256;
+    const bool dvec = (g.Cout & 3) == 0;
+    float4 dv[D_V4 > 0 ? D_V4 : 1];
+    float ds[D_S];
+    float4 xv[FAST ? (X_V4 > 0 ? X_V4 : 1) : 1];
+    float xs[FAST ? 1 : X_S];
+
+    auto load_tile = [&](int buf) {
+        // dz tile: rows = positions, cols = co (contiguous in memory)
+        if (dvec && D_V4 > 0) {
+            constexpr int CH = BM / 4;        // float4 chunks per row
+            constexpr int RP = 256 / CH;      // rows per pass
+            const int ch = tid % CH, r0 = tid / CH;
+#pragma unroll
+            for (int i = 0; i < (D_V4 > 0 ? D_V4 : 1); ++i) {
+                const RowInfo ri = rows[buf][r0 + RP * i];
+                const int co = co0 + ch * 4;
+                dv[i] = (ri.base >= 0 && co < g.Cout)
+                            ? *reinterpret_cast<const float4*>(dz + (size_t)ri.out_off + co)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int cc = tid % BM, r0 = tid / BM;
+            constexpr int RP = 256 / BM > 0 ? 256 / BM : 1;
+#pragma unroll
+            for (int i = 0; i < D_S; ++i) {
+                const RowInfo ri = rows[buf][r0 + RP * i];
+                const int co = co0 + cc;
+                ds[i] = (ri.base >= 0 && co < g.Cout) ? dz[(size_t)ri.out_off + co] : 0.f;
+            }
+        }
+        if constexpr (FAST) {
+            constexpr int CH = BN / 4;
+            constexpr int RP = 256 / CH;
+            const int ch = tid % CH, r0 = tid / CH;
+            const int tap = j0 / Ct;
+            const int c0 = j0 - tap * Ct + ch * 4;
+            const int td = taps[tap];
+#pragma unroll
+            for (int i = 0; i < X_V4; ++i) {
+                const RowInfo ri = rows[buf][r0 + RP * i];
+                int pix;
+                bool ok = tap_pixel(g, ri, td, pix);
+                xv[i] = ok ? *reinterpret_cast<const float4*>(x1 + (size_t)pix * g.C1 + c0)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int jj = tid % BN, r0 = tid / BN;
+            constexpr int RP = 256 / BN;
+            const int k = j0 + jj;
+            const bool kv = k < K;
+            const int tap = kv ? k / Ct : 0;
+            const int c = k - tap * Ct;
+            const int td = taps[tap];
+            const bool second = c >= g.C1;
+            const float* src = second ? x2 : x1;
+            const int cs = second ? g.C2 : g.C1;
+            const int cc = second ? c - g.C1 : c;
+#pragma unroll
+            for (int i = 0; i < X_S; ++i) {
+                const RowInfo ri = rows[buf][r0 + RP * i];
+                int pix;
+                bool ok = tap_pixel(g, ri, td, pix) && kv;
+                xs[i] = ok ? src[(size_t)pix * cs + cc] : 0.f;
+            }
+        }
+    };
+
+    auto store_tile = [&]() {
+        if (dvec && D_V4 > 0) {
+            constexpr int CH = BM / 4;
+            constexpr int RP = 256 / CH;
+            const int ch = tid % CH, r0 = tid / CH;
+#pragma unroll
+            for (int i = 0; i < (D_V4 > 0 ? D_V4 : 1); ++i)
+                *reinterpret_cast<float4*>(&Ds[(r0 + RP * i) * BM + ch * 4]) = dv[i];
+        } else {
+            const int cc = tid % BM, r0 = tid / BM;
+            constexpr int RP = 256 / BM > 0 ? 256 / BM : 1;
+#pragma unroll
+            for (int i = 0; i < D_S; ++i) Ds[(r0 + RP * i) * BM + cc] = ds[i];
+        }
+        if constexpr (FAST) {
+            constexpr int CH = BN / 4;
+            constexpr int RP = 256 / CH;
+            const int ch = tid % CH, r0 = tid / CH;
+#pragma unroll
+            for (int i = 0; i < X_V4; ++i) *reinterpret_cast<float4*>(&Xs[(r0 + RP * i) * BN + ch * 4]) = xv[i];
+        } else {
+            const int jj = tid % BN, r0 = tid / BN;
+            constexpr int RP = 256 / BN;
+#pragma unroll
+            for (int i = 0; i < X_S; ++i) Xs[(r0 + RP * i) * BN + jj] = xs[i];
+        }
+    };
+
+    auto decode_rows = [&](int slice, int buf) {
+        if (tid < BP) {
+            rows[buf][tid] = decode_row(g, slice * BP + tid, M, false);
+        }
+    };
+
+    const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    if (s_begin < s_end) {
+        decode_rows(s_begin, 0);
+        __syncthreads();
+        load_tile(0);
+        store_tile();
+        if (s_begin + 1 < s_end) decode_rows(s_begin + 1, 1);
+        __syncthreads();
+        for (int s = s_begin; s < s_end; ++s) {
+            const int nb = (s - s_begin + 1) & 1;
+            const bool more = s + 1 < s_end;
+            if (more) load_tile(nb);  // in flight under the MFMAs
+#pragma unroll 4
+            for (int p = 0; p < BP / 2; ++p) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = Ds[(2 * p + lh) * BM + wm0 + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Xs[(2 * p + lh) * BN + wn0 + j * 32 + l31];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                store_tile();
+                if (s + 2 < s_end) decode_rows(s + 2, nb ^ 1);
+                __syncthreads();
+            }
+        }
+    }
+
+    float* dst = out + (size_t)split * g.Cout * K;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = j0 + wn0 + j * 32 + l31;
+        if (col >= K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < g.Cout) dst[(size_t)row * K + col] = acc[i][j][r];
+            }
+    }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n, int splits,
+                                     int accumulate) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? dw[i] : 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
+    dw[i] = s;
+}
+
+// column sums of dz[M][C] (bias gradient): stage 1 partials per row chunk, stage 2 ordered sum
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dz, float* __restrict__ part,
+                                                             int M, int C, int rows_per_chunk) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int r_begin = blockIdx.y * rows_per_chunk;
+    const int r_end = min(r_begin + rows_per_chunk, M);
+    float s = 0.f;
+    if (c < C)
+        for (int r = r_begin + rl; r < r_end; r += 4) s += dz[(size_t)r * C + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) part[(size_t)blockIdx.y * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int chunks,
+                                    int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = accumulate ? out[c] : 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * C + c];
+    out[c] = s;
+}
+
+struct TapMap {
+    int32_t t[CG_MAX_TAPS];
+};
+// out[ci - ci0][tc][co] = w[co][tapmap[tc]][ci]; 32x32 LDS-tiled transpose per tap
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                               int Cout, int T, int Cin, int ci0, int nci, TapMap tm,
+                                                               int Tc) {
+    __shared__ float tile[32][33];
+    const int tc = blockIdx.z;
+    const int tap = tm.t[tc];
+    const int cib = blockIdx.x * 32, cob = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        int co = cob + r, ci = cib + tx;
+        tile[r][tx] = (co < Cout && ci < nci) ? w[((size_t)co * T + tap) * Cin + ci0 + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int ci = cib + r, co = cob + tx;
+        if (ci < nci && co < Cout) out[((size_t)ci * Tc + tc) * Cout + co] = tile[tx][r];
+    }
+}
+
+// ---- opt-in launch timing ---------------------------------------------------------------------
+struct ProfRec {
+    int slot;
+    double flops;
+    hipEvent_t e0, e1;
+};
+std::mutex prof_mu;
+bool prof_on = false;
+std::vector<ProfRec> prof_recs;
+char prof_names[CG_PROF_SLOTS][64];
+
+int tile_id(int bm, int bn) {
+    if (bm == 128 && bn == 128) return 0;
+    if (bm == 128 && bn == 64) return 1;
+    if (bm == 128 && bn == 32) return 2;
+    if (bm == 64 && bn == 128) return 3;
+    if (bm == 64 && bn == 64) return 4;
+    if (bm == 32 && bn == 128) return 5;
+    return 6;
+}
+struct ProfScope {
+    bool active = false;
+    ProfRec rec;
+    hipStream_t st;
+    ProfScope(int family, int bm, int bn, bool fast, double flops, hipStream_t s) : st(s) {
+        if (!prof_on) return;
+        active = true;
+        rec.slot = family * 16 + tile_id(bm, bn) * 2 + (fast ? 1 : 0);
+        rec.flops = flops;
+        snprintf(prof_names[rec.slot], sizeof(prof_names[0]), "%s<%d,%d,%s>", family ? "conv_wgrad_kernel" : "conv_fwd_kernel",
+                 bm, bn, fast ? "fast" : "generic");
+        hipEventCreate(&rec.e0);
+        hipEventCreate(&rec.e1);
+        hipEventRecord(rec.e0, st);
+    }
+    ~ProfScope() {
+        if (!active) return;
+        hipEventRecord(rec.e1, st);
+        std::lock_guard<std::mutex> lk(prof_mu);
+        prof_recs.push_back(rec);
+    }
+};
+
+int validate_geom(const cg_conv_geom* g, const char* who) {
+    CG_CHECK_ARG(g != nullptr, "%s: null geometry", who);
+    CG_CHECK_ARG(g->T >= 1 && g->T <= CG_MAX_TAPS, "%s: T=%d out of range", who, g->T);
+    CG_CHECK_ARG(g->N > 0 && g->H > 0 && g->W > 0 && g->C1 > 0 && g->C2 >= 0 && g->Cout > 0, "%s: bad dims", who);
+    CG_CHECK_ARG(g->Ho > 0 && g->Wo > 0 && g->HoF > 0 && g->WoF > 0 && g->stride > 0, "%s: bad output dims", who);
+    CG_CHECK_ARG(g->up == 0 || g->up == 1, "%s: up must be 0/1", who);
+    const double in_elems = (double)g->N * g->H * g->W * (g->C1 + g->C2);
+    const double out_elems = (double)g->N * g->HoF * g->WoF * g->Cout;
+    CG_CHECK_ARG(in_elems < 2.0e9 && out_elems < 2.0e9, "%s: tensor exceeds 2^31 elements", who);
+    return CG_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias, float* y,
+               int M, int K, bool fast, hipStream_t st) {
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (g->Cout + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n), block(256);
+    ProfScope prof(0, BM, BN, fast, 2.0 * (double)M * (double)g->Cout * (double)K, st);
+    if (fast)
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, *g, x1, x2, w, bias, y, M, K,
+                           tiles_n);
+    else
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), grid, block, 0, st, *g, x1, x2, w, bias, y, M, K,
+                           tiles_n);
+    CG_LAUNCH_CHECK("conv_fwd_kernel");
+    return CG_OK;
+}
+
+struct WgradPlan {
+    int bm, bn;
+    bool fast;
+    int tiles_m, tiles_n, splits, slices_per_split;
+};
+
+WgradPlan plan_wgrad(const cg_conv_geom* g) {
+    // Every instantiated tile has exactly four 32x32 MFMA wave tiles or more (4 waves / block):
+    //   bm=128: bn in {128, 64, 32};  bm=64: bn in {128, 64};  bm=32: bn = 128.
+    // FAST (float4 gather, one tap per k-tile) needs a single source and Ct % bn == 0.
+    WgradPlan p;
+    const int Ct = g->C1 + g->C2;
+    const int K = g->T * Ct;
+    const int M = g->N * g->Ho * g->Wo;
+    p.bm = g->Cout > 64 ? 128 : (g->Cout > 32 ? 64 : 32);
+    const int bn_min = p.bm == 128 ? 32 : (p.bm == 64 ? 64 : 128);
+    p.fast = false;
+    p.bn = 0;
+    if (g->C2 == 0) {
+        for (int bn = 128; bn >= bn_min; bn >>= 1)
+            if (Ct % bn == 0) { p.bn = bn; p.fast = true; break; }
+    }
+    if (!p.fast) {
+        p.bn = bn_min;
+        while (p.bn < 128 && p.bn < K) p.bn <<= 1;
+        if (p.bn > 128) p.bn = 128;
+    }
+    p.tiles_m = (g->Cout + p.bm - 1) / p.bm;
+    p.tiles_n = (K + p.bn - 1) / p.bn;
+    const int slices = (M + 31) / 32;
+    const int tiles = p.tiles_m * p.tiles_n;
+    int want = (2 * 256 + tiles - 1) / tiles;          // ~2 blocks per CU
+    int max_by_work = slices / 8 > 0 ? slices / 8 : 1; // >= 8 slices (256 positions) per split
+    int s = want < max_by_work ? want : max_by_work;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    p.slices_per_split = (slices + s - 1) / s;
+    p.splits = (slices + p.slices_per_split - 1) / p.slices_per_split;
+    return p;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_wgrad(const cg_conv_geom* g, const WgradPlan& p, const float* x1, const float* x2, const float* dz,
+                 float* out, int M, int K, hipStream_t st) {
+    dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits), block(256);
+    ProfScope prof(1, BM, BN, p.fast, 2.0 * (double)M * (double)g->Cout * (double)K, st);
+    if (p.fast)
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, *g, x1, x2, dz, out, M, K,
+                           p.tiles_n, p.slices_per_split);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, false>), grid, block, 0, st, *g, x1, x2, dz, out, M, K,
+                           p.tiles_n, p.slices_per_split);
+    CG_LAUNCH_CHECK("conv_wgrad_kernel");
+    return CG_OK;
+}
+
+constexpr int COLSUM_ROWS = 512;
+
+}  // namespace
+
+extern "C" int cg_conv2d_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
+                             const float* bias, float* y, cg_stream_t stream) {
+    int rc = validate_geom(g, "cg_conv2d_fwd");
+    if (rc) return rc;
+    CG_CHECK_ARG(x1 && w && y, "cg_conv2d_fwd: null pointer");
+    CG_CHECK_ARG(g->C2 == 0 || x2, "cg_conv2d_fwd: C2 > 0 needs x2");
+    const int Ct = g->C1 + g->C2;
+    const int K = g->T * Ct;
+    const int M = g->N * g->Ho * g->Wo;
+    const bool fast = (g->C2 == 0) && (Ct % 32 == 0);
+    hipStream_t st = cg_s(stream);
+    const long blocks128 = (long)((M + 127) / 128) * ((g->Cout + 127) / 128);
+    if (g->Cout > 64) {
+        if (blocks128 < 128) return launch_fwd<64, 64, 32, 32>(g, x1, x2, w, bias, y, M, K, fast, st);
+        return launch_fwd<128, 128, 64, 64>(g, x1, x2, w, bias, y, M, K, fast, st);
+    }
+    if (g->Cout > 32) {
+        if ((M + 127) / 128 < 128) return launch_fwd<64, 64, 32, 32>(g, x1, x2, w, bias, y, M, K, fast, st);
+        return launch_fwd<128, 64, 64, 32>(g, x1, x2, w, bias, y, M, K, fast, st);
+    }
+    return launch_fwd<128, 32, 32, 32>(g, x1, x2, w, bias, y, M, K, fast, st);
+}
+
+extern "C" size_t cg_conv2d_wgrad_workspace(const cg_conv_geom* g) {
+    if (!g || g->T < 1 || g->T > CG_MAX_TAPS) return 0;
+    WgradPlan p = plan_wgrad(g);
+    const size_t K = (size_t)g->T * (g->C1 + g->C2);
+    const int M = g->N * g->Ho * g->Wo;
+    const size_t chunks = (M + COLSUM_ROWS - 1) / COLSUM_ROWS;
+    return ((size_t)p.splits * g->Cout * K + chunks * g->Cout) * sizeof(float);
+}
+
+extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const float* x2, const float* dz, float* dw,
+                               float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
+    int rc = validate_geom(g, "cg_conv2d_wgrad");
+    if (rc) return rc;
+    CG_CHECK_ARG(x1 && dz && dw, "cg_conv2d_wgrad: null pointer");
+    CG_CHECK_ARG(g->C2 == 0 || x2, "cg_conv2d_wgrad: C2 > 0 needs x2");
+    const size_t need = cg_conv2d_wgrad_workspace(g);
+    if (!ws || ws_bytes < need) return cg_set_error(CG_ERR_WORKSPACE, "cg_conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
+    const int Ct = g->C1 + g->C2;
+    const int K = g->T * Ct;
+    const int M = g->N * g->Ho * g->Wo;
+    hipStream_t st = cg_s(stream);
+    WgradPlan p = plan_wgrad(g);
+    float* part = (float*)ws;
+    const bool direct = p.splits == 1 && !accumulate;
+    float* out = direct ? dw : part;
+#define WG(BM_, BN_, WM_, WN_) rc = launch_wgrad<BM_, BN_, WM_, WN_>(g, p, x1, x2, dz, out, M, K, st)
+    if (p.bm == 128 && p.bn == 128) WG(128, 128, 64, 64);
+    else if (p.bm == 128 && p.bn == 64) WG(128, 64, 64, 32);
+    else if (p.bm == 128 && p.bn == 32) WG(128, 32, 32, 32);
+    else if (p.bm == 64 && p.bn == 128) WG(64, 128, 32, 64);
+    else if (p.bm == 64 && p.bn == 64) WG(64, 64, 32, 32);
+    else if (p.bm == 32 && p.bn == 128) WG(32, 128, 32, 32);
+    else return cg_set_error(CG_ERR_ARG, "cg_conv2d_wgrad: no tile for %dx%d", p.bm, p.bn);
+#undef WG
+    if (rc) return rc;
+    if (!direct) {
+        const size_t n = (size_t)g->Cout * K;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cg_div_up(n, 256)), dim3(256), 0, st, part, dw, n, p.splits,
+                           accumulate);
+        CG_LAUNCH_CHECK("splitk_reduce_kernel");
+    }
+    if (dbias) {
+        float* cpart = part + (size_t)p.splits * g->Cout * K;
+        const int chunks = (M + COLSUM_ROWS - 1) / COLSUM_ROWS;
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cg_div_up(g->Cout, 64), chunks), dim3(256), 0, st, dz, cpart, M,
+                           g->Cout, COLSUM_ROWS);
+        CG_LAUNCH_CHECK("colsum_partial_kernel");
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cg_div_up(g->Cout, 256)), dim3(256), 0, st, cpart, dbias, g->Cout,
+                           chunks, accumulate);
+        CG_LAUNCH_CHECK("colsum_final_kernel");
+    }
+    return CG_OK;
+}
+
+extern "C" int cg_weight_transpose(const float* w, float* out, int Cout, int T, int Cin, int ci0, int nci,
+                                   const int32_t* tapmap_host, int Tc, cg_stream_t stream) {
+    CG_CHECK_ARG(w && out && tapmap_host, "cg_weight_transpose: null pointer");
+    CG_CHECK_ARG(Tc >= 1 && Tc <= CG_MAX_TAPS && T >= 1 && ci0 >= 0 && nci >= 1 && ci0 + nci <= Cin,
+                 "cg_weight_transpose: bad sizes");
+    TapMap tm;
+    memset(&tm, 0, sizeof(tm));
+    for (int i = 0; i < Tc; ++i) {
+        CG_CHECK_ARG(tapmap_host[i] >= 0 && tapmap_host[i] < T, "cg_weight_transpose: tap %d out of range", tapmap_host[i]);
+        tm.t[i] = tapmap_host[i];
+    }
+    dim3 grid(cg_div_up(nci, 32), cg_div_up(Cout, 32), Tc);
+    hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, cg_s(stream), w, out, Cout, T, Cin, ci0, nci, tm, Tc);
+    CG_LAUNCH_CHECK("weight_transpose_kernel");
+    return CG_OK;
+}
+
+extern "C" int cg_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(prof_mu);
+    prof_on = on != 0;
+    return CG_OK;
+}
+
+extern "C" int cg_prof_collect(int64_t* counts, double* ms, double* flops) {
+    CG_CHECK_ARG(counts && ms && flops, "cg_prof_collect: null pointer");
+    std::lock_guard<std::mutex> lk(prof_mu);
+    for (int i = 0; i < CG_PROF_SLOTS; ++i) {
+        counts[i] = 0;
+        ms[i] = 0.0;
+        flops[i] = 0.0;
+    }
+    for (auto& r : prof_recs) {
+        hipEventSynchronize(r.e1);
+        float t = 0.f;
+        hipEventElapsedTime(&t, r.e0, r.e1);
+        counts[r.slot] += 1;
+        ms[r.slot] += (double)t;
+        flops[r.slot] += r.flops;
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+    }
+    prof_recs.clear();
+    return CG_OK;
+}
+
+extern "C" const char* cg_prof_slot_name(int slot) {
+    if (slot < 0 || slot >= CG_PROF_SLOTS) return "";
+    return prof_names[slot];
+}

@@ -1,0 +1,543 @@
+// HBM-bound elementwise / stencil / reduction kernels of the Council-GAN step (gfx950).
+// Each cites the reference arithmetic it replaces.  All are grid-stride, 256-thread blocks,
+// coalesced along the contiguous channel dimension of NHWC.
+#include <stdarg.h>
+#include <math.h>
+#include "cg_common.h"
+
+thread_local char cg_err_buf[512] = {0};
+
+int cg_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(cg_err_buf, sizeof(cg_err_buf), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* cg_last_error(void) { return cg_err_buf; }
+extern "C" int cg_version(void) { return 100; }
+
+namespace {
+
+inline unsigned ew_grid(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+#define GRID_STRIDE(i, n) \
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dz,
+                               size_t n, int act) {
+    GRID_STRIDE(i, n) dz[i] = dy[i] * cg_act_grad_from_out(y[i], act);
+}
+
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act) {
+    GRID_STRIDE(i, n) y[i] = cg_apply_act(x[i], act);
+}
+__global__ void fill_kernel(float* __restrict__ p, size_t n, float v) { GRID_STRIDE(i, n) p[i] = v; }
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
+    GRID_STRIDE(i, n) o[i] = a[i] + b[i];
+}
+__global__ void axpby_kernel(float alpha, const float* __restrict__ a, float beta, float* __restrict__ b, size_t n) {
+    GRID_STRIDE(i, n) b[i] = alpha * a[i] + (beta == 0.f ? 0.f : beta * b[i]);
+}
+
+// ---- AvgPool2d(3, stride 2, pad 1, count_include_pad=False): networks.py:32,129 ---------------
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+                                   int Ho, int Wo) {
+    const size_t total = (size_t)N * Ho * Wo * C;
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C);
+        size_t p = i / C;
+        int ox = (int)(p % Wo);
+        p /= Wo;
+        int oy = (int)(p % Ho);
+        int n = (int)(p / Ho);
+        int y0 = max(2 * oy - 1, 0), y1 = min(2 * oy + 1, H - 1);
+        int x0 = max(2 * ox - 1, 0), x1 = min(2 * ox + 1, W - 1);
+        float s = 0.f;
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) s += x[(((size_t)n * H + yy) * W + xx) * C + c];
+        y[i] = s / (float)((y1 - y0 + 1) * (x1 - x0 + 1));
+    }
+}
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C,
+                                   int Ho, int Wo) {
+    const size_t total = (size_t)N * H * W * C;
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C);
+        size_t p = i / C;
+        int ix = (int)(p % W);
+        p /= W;
+        int iy = (int)(p % H);
+        int n = (int)(p / H);
+        // windows containing (iy, ix): oy in [ceil((iy-1)/2), floor((iy+1)/2)]
+        int oy0 = max(iy / 2, 0), oy1 = min((iy + 1) / 2, Ho - 1);
+        int ox0 = max(ix / 2, 0), ox1 = min((ix + 1) / 2, Wo - 1);
+        float s = 0.f;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            int ny = min(2 * oy + 1, H - 1) - max(2 * oy - 1, 0) + 1;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                int nx = min(2 * ox + 1, W - 1) - max(2 * ox - 1, 0) + 1;
+                s += dy[(((size_t)n * Ho + oy) * Wo + ox) * C + c] / (float)(ny * nx);
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+// ---- nearest 2x upsample, networks.py:385 -----------------------------------------------------
+__global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+    const size_t total = (size_t)N * 2 * H * 2 * W * C;
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C);
+        size_t p = i / C;
+        int ox = (int)(p % (2 * W));
+        p /= 2 * W;
+        int oy = (int)(p % (2 * H));
+        int n = (int)(p / (2 * H));
+        y[i] = x[(((size_t)n * H + (oy >> 1)) * W + (ox >> 1)) * C + c];
+    }
+}
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C) {
+    const size_t total = (size_t)N * H * W * C;
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C);
+        size_t p = i / C;
+        int ix = (int)(p % W);
+        p /= W;
+        int iy = (int)(p % H);
+        int n = (int)(p / H);
+        const size_t rs = (size_t)2 * W * C;
+        const size_t b = (((size_t)n * 2 * H + 2 * iy) * 2 * W + 2 * ix) * C + c;
+        dx[i] = (dy[b] + dy[b + C]) + (dy[b + rs] + dy[b + rs + C]);
+    }
+}
+
+// ---- AdaptiveAvgPool2d(1), networks.py:347 -----------------------------------------------------
+__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C) {
+    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
+    double s = 0.0;
+    if (c < C)
+        for (int r = rl; r < HW; r += 4) s += (double)x[((size_t)n * HW + r) * C + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) y[(size_t)n * C + c] = (float)((red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / HW);
+}
+
+// ---- mask / blend head, networks.py:398-407 ----------------------------------------------------
+// od (image channels) and k (number of masks) are template parameters so the per-pixel arrays stay
+// in registers (a runtime-indexed local array would live in scratch).
+template <int OD, int K>
+__global__ void mask_blend_fwd_kernel(const float* __restrict__ nx, const float* __restrict__ im_in,
+                                      float* __restrict__ im_out, float* __restrict__ mask, size_t npix) {
+    constexpr int CH = OD * K + K;
+    GRID_STRIDE(p, npix) {
+        float v[CH], im[OD];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) v[c] = nx[p * CH + c];
+#pragma unroll
+        for (int c = 0; c < OD; ++c) im[c] = im_in[p * OD + c];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float m = (tanhf(10.f * v[OD * K + j]) + 1.f) * 0.5f;
+            mask[p * K + j] = m;
+#pragma unroll
+            for (int c = 0; c < OD; ++c) im[c] = (1.f - m) * im[c] + m * v[OD * j + c];
+        }
+#pragma unroll
+        for (int c = 0; c < OD; ++c) im_out[p * OD + c] = im[c];
+    }
+}
+template <int OD, int K>
+__global__ void mask_blend_bwd_kernel(const float* __restrict__ nx, const float* __restrict__ im_in,
+                                      const float* __restrict__ d_out, const float* __restrict__ d_mask,
+                                      float* __restrict__ d_nx, size_t npix) {
+    constexpr int CH = OD * K + K;
+    GRID_STRIDE(p, npix) {
+        float v[CH], ims[K][OD], m[K], th[K], g[OD];  // ims[j] = image entering blend step j
+#pragma unroll
+        for (int c = 0; c < CH; ++c) v[c] = nx[p * CH + c];
+#pragma unroll
+        for (int c = 0; c < OD; ++c) ims[0][c] = im_in[p * OD + c];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            th[j] = tanhf(10.f * v[OD * K + j]);
+            m[j] = (th[j] + 1.f) * 0.5f;
+            if (j + 1 < K) {
+#pragma unroll
+                for (int c = 0; c < OD; ++c) ims[j + 1 < K ? j + 1 : 0][c] = (1.f - m[j]) * ims[j][c] + m[j] * v[OD * j + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < OD; ++c) g[c] = d_out[p * OD + c];
+#pragma unroll
+        for (int j = K - 1; j >= 0; --j) {
+            float dm = d_mask ? d_mask[p * K + j] : 0.f;
+#pragma unroll
+            for (int c = 0; c < OD; ++c) {
+                d_nx[p * CH + OD * j + c] = g[c] * m[j];
+                dm += g[c] * (v[OD * j + c] - ims[j][c]);
+                g[c] *= (1.f - m[j]);
+            }
+            // d/dt (tanh(10 t) + 1)/2 = 5 (1 - tanh^2(10 t))
+            d_nx[p * CH + OD * K + j] = dm * 5.f * (1.f - th[j] * th[j]);
+        }
+    }
+}
+
+// ---- LSGAN, networks.py:64,90,166,194 ------------------------------------------------------------
+__global__ __launch_bounds__(256) void lsgan_fwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                        const float* __restrict__ wt, int nb, int hw, int group,
+                                                        float* __restrict__ loss, int accumulate) {
+    __shared__ double red[4];
+    double s = 0.0;
+    const int total = nb * hw;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int sidx = i / hw;
+        const float d = out[i] - tgt[sidx];
+        s += (double)wt[sidx] * (double)d * (double)d;
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = (red[0] + red[1] + red[2] + red[3]) / ((double)group * hw);
+        loss[0] = (accumulate ? loss[0] : 0.f) + (float)t;
+    }
+}
+__global__ void lsgan_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                 const float* __restrict__ wt, const float* __restrict__ gscale, int nb, int hw,
+                                 int group, float* __restrict__ d_out) {
+    const size_t total = (size_t)nb * hw;
+    const float gs = gscale[0] * 2.f / ((float)group * (float)hw);
+    GRID_STRIDE(i, total) {
+        const int sidx = (int)(i / hw);
+        d_out[i] = gs * wt[sidx] * (out[i] - tgt[sidx]);
+    }
+}
+
+// ---- focus-loss criteria, trainer_council.py:230-250 ------------------------------------------
+__global__ __launch_bounds__(1024) void focus_sums_kernel(const float* __restrict__ mask, int N, int H, int W, int k,
+                                                          float center, float eps, float* __restrict__ sums) {
+    __shared__ double red[3][16];
+    const size_t total = (size_t)N * H * W * k;
+    double a = 0.0, b = 0.0, t = 0.0;
+    for (size_t i = threadIdx.x; i < total; i += 1024) {
+        const float m = mask[i];
+        size_t p = i / k;
+        const int x = (int)(p % W);
+        p /= W;
+        const int y = (int)(p % H);
+        a += 1.0 / ((double)fabsf(m - center) + (double)eps);
+        b += (double)m;
+        if (y + 1 < H) t += (double)fabsf(mask[i + (size_t)W * k] - m);
+        if (x + 1 < W) t += (double)fabsf(mask[i + k] - m);
+    }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    t = wave_sum_d(t);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a;
+        red[1][threadIdx.x >> 6] = b;
+        red[2][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += red[threadIdx.x][w];
+        sums[threadIdx.x] = (float)s;
+    }
+}
+__global__ void focus_total_kernel(const float* __restrict__ sums, float numel, float w_zo, float w_total, float w_tv,
+                                   int use_abs, int use_square, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float zo = sums[0] / numel;                       // trainer_council.py:230-231
+    float small = 0.f;
+    if (use_abs) small += fabsf(sums[1]) / numel;           // :245-246
+    if (use_square) small += (sums[1] / numel) * (sums[1] / numel);  // :242-243
+    const float tv = sums[2] / numel;                       // :248-250
+    out[0] = w_zo * zo + w_total * small + w_tv * tv;
+    out[1] = zo;
+    out[2] = small;
+    out[3] = tv;
+}
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+__global__ void focus_bwd_kernel(const float* __restrict__ mask, const float* __restrict__ sums,
+                                 const float* __restrict__ gscale, int N, int H, int W, int k, float center, float eps,
+                                 float w_zo, float w_total, float w_tv, int use_abs, int use_square,
+                                 float* __restrict__ d_mask) {
+    const size_t total = (size_t)N * H * W * k;
+    const float numel = (float)total;
+    const float gs = gscale[0];
+    // mask_small: abs -> |sum m|/numel ; square -> (sum m/numel)^2   (trainer_council.py:242-246)
+    float dsmall = 0.f;
+    if (use_abs) dsmall += sgn(sums[1]) / numel;
+    if (use_square) dsmall += 2.f * sums[1] / (numel * numel);
+    GRID_STRIDE(i, total) {
+        const float m = mask[i];
+        size_t p = i / k;
+        const int x = (int)(p % W);
+        p /= W;
+        const int y = (int)(p % H);
+        float g = 0.f;
+        if (w_zo != 0.f) {
+            const float d = m - center;
+            const float den = fabsf(d) + eps;
+            g += w_zo * (-sgn(d) / (den * den)) / numel;
+        }
+        if (w_total != 0.f) g += w_total * dsmall;
+        if (w_tv != 0.f) {
+            float tv = 0.f;
+            const size_t rs = (size_t)W * k;
+            if (y + 1 < H) tv -= sgn(mask[i + rs] - m);
+            if (y > 0) tv += sgn(m - mask[i - rs]);
+            if (x + 1 < W) tv -= sgn(mask[i + k] - m);
+            if (x > 0) tv += sgn(m - mask[i - k]);
+            g += w_tv * tv / numel;
+        }
+        d_mask[i] = gs * g;
+    }
+}
+
+// ---- L1 mean (recon / council-abs criteria), trainer_council.py:207-208,227-228 ----------------
+__global__ __launch_bounds__(1024) void l1_mean_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           size_t n, float* __restrict__ loss) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) s += (double)fabsf(a[i] - b[i]);
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        loss[0] = (float)(t / (double)n);
+    }
+}
+__global__ void l1_mean_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                   const float* __restrict__ gscale, size_t n, float* __restrict__ da) {
+    const float gs = gscale[0] / (float)n;
+    GRID_STRIDE(i, n) da[i] = gs * sgn(a[i] - b[i]);
+}
+
+// ---- torch.optim.Adam (L2 weight decay), trainer_council.py:170-179 ----------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, float beta1, float beta2, float eps, float wd,
+                            float step_size, float bc2_sqrt) {
+    const float w1 = 1.f - beta1;
+    GRID_STRIDE(i, n) {
+        const float pi = p[i];
+        const float gi = g[i] + wd * pi;                      // grad.add(param, alpha=weight_decay)
+        float mi = m[i];
+        // exp_avg.lerp_(grad, 1 - beta1) with ATen's two-sided lerp formula
+        mi = (w1 < 0.5f) ? mi + w1 * (gi - mi) : gi - (gi - mi) * (1.f - w1);
+        const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;  // mul_(beta2).addcmul_(g, g, 1-beta2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                   float* __restrict__ out, int nidx, size_t row_elems) {
+    const size_t total = (size_t)nidx * row_elems;
+    GRID_STRIDE(i, total) {
+        const size_t r = i / row_elems, e = i - r * row_elems;
+        out[i] = src[(size_t)idx[r] * row_elems + e];
+    }
+}
+
+// ring[pos % n] = value ; optional w = mean(ring_a) / mean(ring_b)  (trainer_council.py:518-524,576-581)
+__global__ void ring_kernel(float* __restrict__ ring_a, float* __restrict__ ring_b, int n, int pos,
+                            const float* __restrict__ value, float* __restrict__ w_out, int push_b) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (push_b)
+        ring_b[pos % n] = value[0];
+    else
+        ring_a[pos % n] = value[0];
+    if (w_out) {
+        double sa = 0.0, sb = 0.0;
+        for (int i = 0; i < n; ++i) {
+            sa += (double)ring_a[i];
+            sb += (double)ring_b[i];
+        }
+        w_out[0] = (float)((sa / n) / (sb / n));
+    }
+}
+
+}  // namespace
+
+#define EW_LAUNCH(kernel, n, ...)                                                                  \
+    hipLaunchKernelGGL(kernel, dim3(ew_grid(n)), dim3(256), 0, cg_s(stream), __VA_ARGS__);         \
+    CG_LAUNCH_CHECK(#kernel);                                                                      \
+    return CG_OK
+
+extern "C" int cg_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, cg_stream_t stream) {
+    CG_CHECK_ARG(dy && y && dz, "cg_act_bwd: null pointer");
+    if (n == 0) return CG_OK;
+    EW_LAUNCH(act_bwd_kernel, n, dy, y, dz, n, act);
+}
+extern "C" int cg_act_fwd(const float* x, float* y, size_t n, int act, cg_stream_t stream) {
+    CG_CHECK_ARG(x && y, "cg_act_fwd: null pointer");
+    if (n == 0) return CG_OK;
+    EW_LAUNCH(act_fwd_kernel, n, x, y, n, act);
+}
+extern "C" int cg_fill(float* p, size_t n, float value, cg_stream_t stream) {
+    CG_CHECK_ARG(p, "cg_fill: null pointer");
+    if (n == 0) return CG_OK;
+    EW_LAUNCH(fill_kernel, n, p, n, value);
+}
+extern "C" int cg_add(const float* a, const float* b, float* out, size_t n, cg_stream_t stream) {
+    CG_CHECK_ARG(a && b && out, "cg_add: null pointer");
+    if (n == 0) return CG_OK;
+    EW_LAUNCH(add_kernel, n, a, b, out, n);
+}
+extern "C" int cg_axpby(float alpha, const float* a, float beta, float* b, size_t n, cg_stream_t stream) {
+    CG_CHECK_ARG(a && b, "cg_axpby: null pointer");
+    if (n == 0) return CG_OK;
+    EW_LAUNCH(axpby_kernel, n, alpha, a, beta, b, n);
+}
+
+static inline int pool_out(int h) { return (h - 1) / 2 + 1; }
+
+extern "C" int cg_avgpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, cg_stream_t stream) {
+    CG_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0, "cg_avgpool3s2_fwd: bad args");
+    const int Ho = pool_out(H), Wo = pool_out(W);
+    EW_LAUNCH(avgpool_fwd_kernel, (size_t)N * Ho * Wo * C, x, y, N, H, W, C, Ho, Wo);
+}
+extern "C" int cg_avgpool3s2_bwd(const float* dy, float* dx, int N, int H, int W, int C, cg_stream_t stream) {
+    CG_CHECK_ARG(dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "cg_avgpool3s2_bwd: bad args");
+    const int Ho = pool_out(H), Wo = pool_out(W);
+    EW_LAUNCH(avgpool_bwd_kernel, (size_t)N * H * W * C, dy, dx, N, H, W, C, Ho, Wo);
+}
+extern "C" int cg_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, cg_stream_t stream) {
+    CG_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0, "cg_upsample2x_fwd: bad args");
+    EW_LAUNCH(upsample_fwd_kernel, (size_t)N * 4 * H * W * C, x, y, N, H, W, C);
+}
+extern "C" int cg_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, cg_stream_t stream) {
+    CG_CHECK_ARG(dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "cg_upsample2x_bwd: bad args");
+    EW_LAUNCH(upsample_bwd_kernel, (size_t)N * H * W * C, dy, dx, N, H, W, C);
+}
+extern "C" int cg_global_avgpool_fwd(const float* x, float* y, int N, int HW, int C, cg_stream_t stream) {
+    CG_CHECK_ARG(x && y && N > 0 && HW > 0 && C > 0, "cg_global_avgpool_fwd: bad args");
+    hipLaunchKernelGGL(gap_kernel, dim3(cg_div_up(C, 64), N), dim3(256), 0, cg_s(stream), x, y, HW, C);
+    CG_LAUNCH_CHECK("gap_kernel");
+    return CG_OK;
+}
+
+#define MB_DISPATCH(KERNEL, ...)                                                                         \
+    do {                                                                                                 \
+        const unsigned grid__ = ew_grid(npix);                                                           \
+        if (od == 3 && k == 3) hipLaunchKernelGGL((KERNEL<3, 3>), dim3(grid__), dim3(256), 0, cg_s(stream), __VA_ARGS__); \
+        else if (od == 3 && k == 1) hipLaunchKernelGGL((KERNEL<3, 1>), dim3(grid__), dim3(256), 0, cg_s(stream), __VA_ARGS__); \
+        else if (od == 3 && k == 2) hipLaunchKernelGGL((KERNEL<3, 2>), dim3(grid__), dim3(256), 0, cg_s(stream), __VA_ARGS__); \
+        else if (od == 3 && k == 4) hipLaunchKernelGGL((KERNEL<3, 4>), dim3(grid__), dim3(256), 0, cg_s(stream), __VA_ARGS__); \
+        else if (od == 1 && k == 1) hipLaunchKernelGGL((KERNEL<1, 1>), dim3(grid__), dim3(256), 0, cg_s(stream), __VA_ARGS__); \
+        else if (od == 1 && k == 2) hipLaunchKernelGGL((KERNEL<1, 2>), dim3(grid__), dim3(256), 0, cg_s(stream), __VA_ARGS__); \
+        else if (od == 1 && k == 3) hipLaunchKernelGGL((KERNEL<1, 3>), dim3(grid__), dim3(256), 0, cg_s(stream), __VA_ARGS__); \
+        else if (od == 1 && k == 4) hipLaunchKernelGGL((KERNEL<1, 4>), dim3(grid__), dim3(256), 0, cg_s(stream), __VA_ARGS__); \
+        else return cg_set_error(CG_ERR_ARG, "mask_blend: od must be 1 or 3 and k in 1..4 (got od=%d k=%d)", od, k); \
+    } while (0)
+
+extern "C" int cg_mask_blend_fwd(const float* new_x, const float* im_in, float* im_out, float* mask, size_t npix,
+                                 int od, int k, cg_stream_t stream) {
+    CG_CHECK_ARG(new_x && im_in && im_out && mask, "cg_mask_blend_fwd: null pointer");
+    if (npix == 0) return CG_OK;
+    MB_DISPATCH(mask_blend_fwd_kernel, new_x, im_in, im_out, mask, npix);
+    CG_LAUNCH_CHECK("mask_blend_fwd_kernel");
+    return CG_OK;
+}
+extern "C" int cg_mask_blend_bwd(const float* new_x, const float* im_in, const float* d_im_out, const float* d_mask,
+                                 float* d_new_x, size_t npix, int od, int k, cg_stream_t stream) {
+    CG_CHECK_ARG(new_x && im_in && d_im_out && d_new_x, "cg_mask_blend_bwd: null pointer");
+    if (npix == 0) return CG_OK;
+    MB_DISPATCH(mask_blend_bwd_kernel, new_x, im_in, d_im_out, d_mask, d_new_x, npix);
+    CG_LAUNCH_CHECK("mask_blend_bwd_kernel");
+    return CG_OK;
+}
+
+extern "C" int cg_lsgan_fwd(const float* out, const float* tgt, const float* wt, int nb, int hw, int group,
+                            float* loss, int accumulate, cg_stream_t stream) {
+    CG_CHECK_ARG(out && tgt && wt && loss && nb > 0 && hw > 0 && group > 0, "cg_lsgan_fwd: bad args");
+    hipLaunchKernelGGL(lsgan_fwd_kernel, dim3(1), dim3(256), 0, cg_s(stream), out, tgt, wt, nb, hw, group, loss, accumulate);
+    CG_LAUNCH_CHECK("lsgan_fwd_kernel");
+    return CG_OK;
+}
+extern "C" int cg_lsgan_bwd(const float* out, const float* tgt, const float* wt, const float* gscale, int nb, int hw,
+                            int group, float* d_out, cg_stream_t stream) {
+    CG_CHECK_ARG(out && tgt && wt && gscale && d_out && nb > 0 && hw > 0 && group > 0, "cg_lsgan_bwd: bad args");
+    EW_LAUNCH(lsgan_bwd_kernel, (size_t)nb * hw, out, tgt, wt, gscale, nb, hw, group, d_out);
+}
+
+extern "C" int cg_focus_sums(const float* mask, int N, int H, int W, int k, float center, float eps, float* sums,
+                             cg_stream_t stream) {
+    CG_CHECK_ARG(mask && sums && N > 0 && H > 0 && W > 0 && k > 0, "cg_focus_sums: bad args");
+    hipLaunchKernelGGL(focus_sums_kernel, dim3(1), dim3(1024), 0, cg_s(stream), mask, N, H, W, k, center, eps, sums);
+    CG_LAUNCH_CHECK("focus_sums_kernel");
+    return CG_OK;
+}
+extern "C" int cg_focus_total(const float* sums, size_t numel, float w_zo, float w_total, float w_tv, int use_abs,
+                              int use_square, float* out, cg_stream_t stream) {
+    CG_CHECK_ARG(sums && out && numel > 0, "cg_focus_total: bad args");
+    hipLaunchKernelGGL(focus_total_kernel, dim3(1), dim3(64), 0, cg_s(stream), sums, (float)numel, w_zo, w_total, w_tv,
+                       use_abs, use_square, out);
+    CG_LAUNCH_CHECK("focus_total_kernel");
+    return CG_OK;
+}
+extern "C" int cg_focus_bwd(const float* mask, const float* sums, const float* gscale, int N, int H, int W, int k,
+                            float center, float eps, float w_zo, float w_total, float w_tv, int use_abs,
+                            int use_square, float* d_mask, cg_stream_t stream) {
+    CG_CHECK_ARG(mask && sums && gscale && d_mask && N > 0 && H > 0 && W > 0 && k > 0, "cg_focus_bwd: bad args");
+    EW_LAUNCH(focus_bwd_kernel, (size_t)N * H * W * k, mask, sums, gscale, N, H, W, k, center, eps, w_zo, w_total, w_tv,
+              use_abs, use_square, d_mask);
+}
+
+extern "C" int cg_l1_mean_fwd(const float* a, const float* b, size_t n, float* loss, cg_stream_t stream) {
+    CG_CHECK_ARG(a && b && loss && n > 0, "cg_l1_mean_fwd: bad args");
+    hipLaunchKernelGGL(l1_mean_fwd_kernel, dim3(1), dim3(1024), 0, cg_s(stream), a, b, n, loss);
+    CG_LAUNCH_CHECK("l1_mean_fwd_kernel");
+    return CG_OK;
+}
+extern "C" int cg_l1_mean_bwd(const float* a, const float* b, const float* gscale, size_t n, float* da,
+                              cg_stream_t stream) {
+    CG_CHECK_ARG(a && b && gscale && da && n > 0, "cg_l1_mean_bwd: bad args");
+    EW_LAUNCH(l1_mean_bwd_kernel, n, a, b, gscale, n, da);
+}
+
+extern "C" int cg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, cg_stream_t stream) {
+    CG_CHECK_ARG(p && g && m && v && step >= 1, "cg_adam_step: bad args");
+    if (n == 0) return CG_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    EW_LAUNCH(adam_kernel, n, p, g, m, v, n, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt);
+}
+
+extern "C" int cg_gather_rows(const float* src, const int32_t* idx_dev, float* out, int nidx, size_t row_elems,
+                              cg_stream_t stream) {
+    CG_CHECK_ARG(src && idx_dev && out && nidx > 0 && row_elems > 0, "cg_gather_rows: bad args");
+    EW_LAUNCH(gather_rows_kernel, (size_t)nidx * row_elems, src, idx_dev, out, nidx, row_elems);
+}
+
+extern "C" int cg_ring_push(float* ring, int n, int pos, const float* value, cg_stream_t stream) {
+    CG_CHECK_ARG(ring && value && n > 0 && pos >= 0, "cg_ring_push: bad args");
+    hipLaunchKernelGGL(ring_kernel, dim3(1), dim3(64), 0, cg_s(stream), ring, (float*)nullptr, n, pos, value,
+                       (float*)nullptr, 0);
+    CG_LAUNCH_CHECK("ring_kernel");
+    return CG_OK;
+}
+extern "C" int cg_loss_match(float* ring_gan, float* ring_council, int n, int pos, const float* council_loss,
+                             float* w_out, cg_stream_t stream) {
+    CG_CHECK_ARG(ring_gan && ring_council && council_loss && w_out && n > 0 && pos >= 0, "cg_loss_match: bad args");
+    hipLaunchKernelGGL(ring_kernel, dim3(1), dim3(64), 0, cg_s(stream), ring_gan, ring_council, n, pos, council_loss,
+                       w_out, 1);
+    CG_LAUNCH_CHECK("ring_kernel");
+    return CG_OK;
+}

@@ -1,0 +1,442 @@
+// InstanceNorm / AdaIN / LayerNorm for NHWC fp32 activations on gfx950.
+//
+// Reference call sites: nn.InstanceNorm2d (networks.py:483), AdaptiveInstanceNorm2d.forward =
+// F.batch_norm on the (1, B*C, H, W) view (networks.py:640-653), LayerNorm.forward
+// (networks.py:670-686).  All of these are HBM-bound passes; statistics are accumulated in
+// fp64 (the vector fp64 rate is far above what HBM can feed) so that E[x^2]-E[x]^2 cannot
+// cancel, then applied in fp32.  Channels are the contiguous dimension, so a wavefront reads
+// 64 consecutive channels of one pixel (coalesced 256 B) and reductions over H*W run down the
+// rows; H*W is split across blocks to fill the 256 CUs and combined in a fixed order
+// (deterministic, no atomics).
+#include "cg_common.h"
+
+namespace {
+
+constexpr int NC_SPLIT_ROWS = 256;  // rows (pixels) per block in the per-(n,c) reductions
+
+__host__ __device__ inline int nc_splits(int HW) { return (HW + NC_SPLIT_ROWS - 1) / NC_SPLIT_ROWS; }
+
+// ws[((n*C + c) * S + s) * 2 + {0,1}] = {sum x, sum x^2} over the rows of split s
+__global__ __launch_bounds__(256) void in_stats_partial(const float* __restrict__ x, double* __restrict__ ws, int HW,
+                                                        int C, int S) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, n = blockIdx.y, s = blockIdx.z;
+    const int r0 = s * NC_SPLIT_ROWS, r1 = min(r0 + NC_SPLIT_ROWS, HW);
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        const float* p = x + (size_t)n * HW * C + c;
+        for (int r = r0 + rl; r < r1; r += 4) {
+            double v = (double)p[(size_t)r * C];
+            a += v;
+            b += v * v;
+        }
+    }
+    red[0][rl][cl] = a;
+    red[1][rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double* o = ws + ((size_t)(n * C + c) * S + s) * 2;
+        o[0] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        o[1] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    }
+}
+
+__global__ void in_stats_final(const double* __restrict__ ws, float* __restrict__ mean, float* __restrict__ rstd,
+                               int NC, int S, int HW, float eps) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < S; ++s) {
+        a += ws[((size_t)i * S + s) * 2];
+        b += ws[((size_t)i * S + s) * 2 + 1];
+    }
+    double m = a / HW;
+    double var = b / HW - m * m;  // biased variance (batch_norm training / InstanceNorm2d)
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// y = act((x - mean) * rstd * gamma + beta) + residual
+template <bool VEC>
+__global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ residual, float* __restrict__ y,
+                                                       size_t total, int HW, int C, int act, int gs) {
+    constexpr int V = VEC ? 4 : 1;
+    const size_t nvec = total / V;
+    const size_t per_n = (size_t)HW * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * V;
+        const int n = (int)(e / per_n);
+        const int c = (int)(e % C);
+        float xv[V], rv[V], ov[V];
+        if constexpr (VEC) {
+            float4 t = *reinterpret_cast<const float4*>(x + e);
+            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            if (residual) {
+                float4 r = *reinterpret_cast<const float4*>(residual + e);
+                rv[0] = r.x; rv[1] = r.y; rv[2] = r.z; rv[3] = r.w;
+            }
+        } else {
+            xv[0] = x[e];
+            if (residual) rv[0] = residual[e];
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int s = n * C + c + k;
+            float z = (xv[k] - mean[s]) * rstd[s];
+            if (gamma) z = z * gamma[n * gs + c + k] + beta[n * gs + c + k];
+            z = cg_apply_act(z, act);
+            if (residual) z += rv[k];
+            ov[k] = z;
+        }
+        if constexpr (VEC)
+            *reinterpret_cast<float4*>(y + e) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        else
+            y[e] = ov[0];
+    }
+}
+
+__device__ __forceinline__ float in_dz(float dy, float xhat, float g, float b, int act) {
+    if (act == CG_ACT_NONE) return dy;
+    float z = xhat * g + b;
+    if (act == CG_ACT_RELU) return z > 0.f ? dy : 0.f;
+    if (act == CG_ACT_LRELU) return z > 0.f ? dy : 0.2f * dy;
+    float t = tanhf(z);
+    return dy * (1.f - t * t);
+}
+
+// ws[((n*C+c)*S + s)*2 + {0,1}] = {sum dz, sum dz*xhat}
+__global__ __launch_bounds__(256) void in_bwd_partial(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      double* __restrict__ ws, int HW, int C, int S, int act, int gs) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, n = blockIdx.y, s = blockIdx.z;
+    const int r0 = s * NC_SPLIT_ROWS, r1 = min(r0 + NC_SPLIT_ROWS, HW);
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        const int sc = n * C + c;
+        const float m = mean[sc], rs = rstd[sc];
+        const float g = gamma ? gamma[n * gs + c] : 1.f, bt = gamma ? beta[n * gs + c] : 0.f;
+        const size_t base = (size_t)n * HW * C + c;
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const size_t e = base + (size_t)r * C;
+            const float xh = (x[e] - m) * rs;
+            const float dz = in_dz(dy[e], xh, g, bt, act);
+            a += (double)dz;
+            b += (double)dz * (double)xh;
+        }
+    }
+    red[0][rl][cl] = a;
+    red[1][rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double* o = ws + ((size_t)(n * C + c) * S + s) * 2;
+        o[0] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        o[1] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    }
+}
+
+// s12[i*2+{0,1}] = {S1/HW, S2/HW} as floats; dgamma = S2, dbeta = S1
+__global__ void in_bwd_final(const double* __restrict__ ws, float* __restrict__ s12, float* __restrict__ dgamma,
+                             float* __restrict__ dbeta, int NC, int S, int HW, int C, int gs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < S; ++s) {
+        a += ws[((size_t)i * S + s) * 2];
+        b += ws[((size_t)i * S + s) * 2 + 1];
+    }
+    s12[i * 2] = (float)(a / HW);
+    s12[i * 2 + 1] = (float)(b / HW);
+    const int gi = (i / C) * gs + (i % C);
+    if (dgamma) dgamma[gi] = (float)b;
+    if (dbeta) dbeta[gi] = (float)a;
+}
+
+// dx = rstd * gamma * (dz - S1/HW - xhat * S2/HW)
+__global__ __launch_bounds__(256) void in_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ s12, float* __restrict__ dx, size_t total,
+                                                    int HW, int C, int act, int gs) {
+    const size_t per_n = (size_t)HW * C;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(e / per_n);
+        const int c = (int)(e % C);
+        const int sc = n * C + c;
+        const float rs = rstd[sc];
+        const float g = gamma ? gamma[n * gs + c] : 1.f, bt = gamma ? beta[n * gs + c] : 0.f;
+        const float xh = (x[e] - mean[sc]) * rs;
+        const float dz = in_dz(dy[e], xh, g, bt, act);
+        dx[e] = rs * g * (dz - s12[sc * 2] - xh * s12[sc * 2 + 1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm (networks.py:670-686): per-sample over D = C*HW, unbiased std, y = (x-mean)/(std+eps)*gamma+beta
+// ---------------------------------------------------------------------------------------
+constexpr int LN_CHUNK = 8192;  // elements per block in the per-sample reductions
+
+__global__ __launch_bounds__(256) void ln_partial(const float* __restrict__ x, const float* __restrict__ dy,
+                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                  double* __restrict__ ws, size_t D, int C, int chunks, int mode) {
+    // mode 0: {sum x, sum x^2};  mode 1: {sum dxhat, sum dxhat*(x-mean)} with dxhat = dy*gamma[c]
+    __shared__ double red[2][4];
+    const int n = blockIdx.y, ch = blockIdx.x;
+    const size_t e0 = (size_t)ch * LN_CHUNK, e1 = min(e0 + (size_t)LN_CHUNK, D);
+    const float* px = x + (size_t)n * D;
+    const float mu = mode ? mean[n] : 0.f;
+    double a = 0.0, b = 0.0;
+    for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        if (mode == 0) {
+            double v = (double)px[e];
+            a += v;
+            b += v * v;
+        } else {
+            float dxh = dy[(size_t)n * D + e] * gamma[e % C];
+            a += (double)dxh;
+            b += (double)dxh * (double)(px[e] - mu);
+        }
+    }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a;
+        red[1][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ws[((size_t)n * chunks + ch) * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        ws[((size_t)n * chunks + ch) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+__global__ void ln_stats_final(const double* __restrict__ ws, float* __restrict__ mean, float* __restrict__ stdv, int N,
+                               int chunks, size_t D) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        a += ws[((size_t)n * chunks + k) * 2];
+        b += ws[((size_t)n * chunks + k) * 2 + 1];
+    }
+    double m = a / (double)D;
+    double var = (b - (double)D * m * m) / (double)(D - 1);  // torch.std default: unbiased
+    if (var < 0.0) var = 0.0;
+    mean[n] = (float)m;
+    stdv[n] = (float)sqrt(var);
+}
+
+__global__ __launch_bounds__(256) void ln_apply(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, const float* __restrict__ mean,
+                                                const float* __restrict__ stdv, float* __restrict__ y, size_t total,
+                                                size_t D, int C, float eps) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(e / D);
+        const int c = (int)(e % C);
+        y[e] = (x[e] - mean[n]) / (stdv[n] + eps) * gamma[c] + beta[c];
+    }
+}
+
+// ab[n*2+{0,1}] = {A, B} summed over chunks
+__global__ void ln_bwd_final(const double* __restrict__ ws, float* __restrict__ ab, int N, int chunks) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        a += ws[((size_t)n * chunks + k) * 2];
+        b += ws[((size_t)n * chunks + k) * 2 + 1];
+    }
+    ab[n * 2] = (float)a;
+    ab[n * 2 + 1] = (float)b;
+}
+
+// dx = inv*(dxhat - A/D) - B*inv^2/((D-1)*std) * (x - mean)
+__global__ __launch_bounds__(256) void ln_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
+                                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                    const float* __restrict__ stdv, const float* __restrict__ ab,
+                                                    float* __restrict__ dx, size_t total, size_t D, int C, float eps) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(e / D);
+        const int c = (int)(e % C);
+        const float sd = stdv[n];
+        const float inv = 1.f / (sd + eps);
+        const float dxh = dy[e] * gamma[c];
+        const float A = ab[n * 2], B = ab[n * 2 + 1];
+        const float k2 = sd > 0.f ? B * inv * inv / ((float)(D - 1) * sd) : 0.f;
+        dx[e] = inv * (dxh - A / (float)D) - k2 * (x[e] - mean[n]);
+    }
+}
+
+// dgamma[c] = sum_{n,hw} dy * xhat ; dbeta[c] = sum dy  -- partial over row chunks then ordered sum
+__global__ __launch_bounds__(256) void ln_dgamma_partial(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ stdv, float* __restrict__ part,
+                                                         int rows_total, int HW, int C, int rows_per_chunk, float eps) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(r0 + rows_per_chunk, rows_total);
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const int n = r / HW;
+            const size_t e = (size_t)r * C + c;
+            const float xh = (x[e] - mean[n]) / (stdv[n] + eps);
+            a += dy[e] * xh;
+            b += dy[e];
+        }
+    red[0][rl][cl] = a;
+    red[1][rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        part[((size_t)blockIdx.y * 2) * C + c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        part[((size_t)blockIdx.y * 2 + 1) * C + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    }
+}
+__global__ void ln_dgamma_final(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                int C, int chunks) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < chunks; ++k) {
+        a += part[((size_t)k * 2) * C + c];
+        b += part[((size_t)k * 2 + 1) * C + c];
+    }
+    dgamma[c] = a;
+    dbeta[c] = b;
+}
+
+constexpr int LN_ROWS = 512;
+inline unsigned ew_grid(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" size_t cg_instnorm_workspace(int N, int HW, int C) {
+    // split partials (doubles) + {S1/HW, S2/HW} floats for the backward apply
+    return (size_t)N * C * nc_splits(HW) * 2 * sizeof(double) + (size_t)N * C * 2 * sizeof(float);
+}
+
+extern "C" int cg_instnorm_stats(const float* x, int N, int HW, int C, float eps, float* mean, float* rstd, void* ws,
+                                 size_t ws_bytes, cg_stream_t stream) {
+    CG_CHECK_ARG(x && mean && rstd && N > 0 && HW > 0 && C > 0, "cg_instnorm_stats: bad args");
+    if (!ws || ws_bytes < cg_instnorm_workspace(N, HW, C))
+        return cg_set_error(CG_ERR_WORKSPACE, "cg_instnorm_stats: workspace too small");
+    const int S = nc_splits(HW);
+    hipLaunchKernelGGL(in_stats_partial, dim3(cg_div_up(C, 64), N, S), dim3(256), 0, cg_s(stream), x, (double*)ws, HW, C, S);
+    CG_LAUNCH_CHECK("in_stats_partial");
+    hipLaunchKernelGGL(in_stats_final, dim3(cg_div_up((size_t)N * C, 256)), dim3(256), 0, cg_s(stream), (const double*)ws,
+                       mean, rstd, N * C, S, HW, eps);
+    CG_LAUNCH_CHECK("in_stats_final");
+    return CG_OK;
+}
+
+extern "C" int cg_instnorm_apply(const float* x, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, int gstride, const float* residual, float* y, int N, int HW, int C,
+                                 int act, cg_stream_t stream) {
+    CG_CHECK_ARG(x && mean && rstd && y && N > 0 && HW > 0 && C > 0, "cg_instnorm_apply: bad args");
+    CG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "cg_instnorm_apply: gamma and beta go together");
+    const size_t total = (size_t)N * HW * C;
+    if ((C & 3) == 0)
+        hipLaunchKernelGGL((in_apply_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, cg_s(stream), x, mean, rstd,
+                           gamma, beta, residual, y, total, HW, C, act, gstride);
+    else
+        hipLaunchKernelGGL((in_apply_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, cg_s(stream), x, mean, rstd,
+                           gamma, beta, residual, y, total, HW, C, act, gstride);
+    CG_LAUNCH_CHECK("in_apply_kernel");
+    return CG_OK;
+}
+
+extern "C" int cg_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, int gstride, float* dx, float* dgamma,
+                               float* dbeta, int N, int HW, int C, int act, void* ws, size_t ws_bytes,
+                               cg_stream_t stream) {
+    CG_CHECK_ARG(dy && x && mean && rstd && dx && N > 0 && HW > 0 && C > 0, "cg_instnorm_bwd: bad args");
+    CG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "cg_instnorm_bwd: gamma and beta go together");
+    if (!ws || ws_bytes < cg_instnorm_workspace(N, HW, C))
+        return cg_set_error(CG_ERR_WORKSPACE, "cg_instnorm_bwd: workspace too small");
+    const int S = nc_splits(HW);
+    double* part = (double*)ws;
+    float* s12 = (float*)(part + (size_t)N * C * S * 2);
+    hipLaunchKernelGGL(in_bwd_partial, dim3(cg_div_up(C, 64), N, S), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma,
+                       beta, part, HW, C, S, act, gstride);
+    CG_LAUNCH_CHECK("in_bwd_partial");
+    hipLaunchKernelGGL(in_bwd_final, dim3(cg_div_up((size_t)N * C, 256)), dim3(256), 0, cg_s(stream), (const double*)part,
+                       s12, dgamma, dbeta, N * C, S, HW, C, gstride);
+    CG_LAUNCH_CHECK("in_bwd_final");
+    const size_t total = (size_t)N * HW * C;
+    hipLaunchKernelGGL(in_bwd_apply, dim3(ew_grid(total)), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma, beta,
+                       (const float*)s12, dx, total, HW, C, act, gstride);
+    CG_LAUNCH_CHECK("in_bwd_apply");
+    return CG_OK;
+}
+
+extern "C" size_t cg_layernorm_workspace(int N, int HW, int C) {
+    const size_t D = (size_t)HW * C;
+    const size_t chunks = (D + LN_CHUNK - 1) / LN_CHUNK;
+    const size_t rows = (size_t)N * HW;
+    const size_t rchunks = (rows + LN_ROWS - 1) / LN_ROWS;
+    return (size_t)N * chunks * 2 * sizeof(double) + (size_t)N * 2 * sizeof(float) + rchunks * 2 * C * sizeof(float);
+}
+
+extern "C" int cg_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                float* stdv, int N, int HW, int C, float eps, void* ws, size_t ws_bytes,
+                                cg_stream_t stream) {
+    CG_CHECK_ARG(x && gamma && beta && y && mean && stdv && N > 0 && HW > 0 && C > 0, "cg_layernorm_fwd: bad args");
+    if (!ws || ws_bytes < cg_layernorm_workspace(N, HW, C))
+        return cg_set_error(CG_ERR_WORKSPACE, "cg_layernorm_fwd: workspace too small");
+    const size_t D = (size_t)HW * C;
+    CG_CHECK_ARG(D > 1, "cg_layernorm_fwd: needs more than one element per sample");
+    const int chunks = (int)((D + LN_CHUNK - 1) / LN_CHUNK);
+    hipLaunchKernelGGL(ln_partial, dim3(chunks, N), dim3(256), 0, cg_s(stream), x, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (double*)ws, D, C, chunks, 0);
+    CG_LAUNCH_CHECK("ln_partial");
+    hipLaunchKernelGGL(ln_stats_final, dim3(cg_div_up(N, 64)), dim3(64), 0, cg_s(stream), (const double*)ws, mean, stdv, N,
+                       chunks, D);
+    CG_LAUNCH_CHECK("ln_stats_final");
+    const size_t total = (size_t)N * D;
+    hipLaunchKernelGGL(ln_apply, dim3(ew_grid(total)), dim3(256), 0, cg_s(stream), x, gamma, beta, (const float*)mean,
+                       (const float*)stdv, y, total, D, C, eps);
+    CG_LAUNCH_CHECK("ln_apply");
+    return CG_OK;
+}
+
+extern "C" int cg_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                const float* stdv, float* dx, float* dgamma, float* dbeta, int N, int HW, int C,
+                                float eps, void* ws, size_t ws_bytes, cg_stream_t stream) {
+    CG_CHECK_ARG(dy && x && gamma && mean && stdv && dx && dgamma && dbeta && N > 0 && HW > 0 && C > 0,
+                 "cg_layernorm_bwd: bad args");
+    if (!ws || ws_bytes < cg_layernorm_workspace(N, HW, C))
+        return cg_set_error(CG_ERR_WORKSPACE, "cg_layernorm_bwd: workspace too small");
+    const size_t D = (size_t)HW * C;
+    const int chunks = (int)((D + LN_CHUNK - 1) / LN_CHUNK);
+    double* part = (double*)ws;
+    float* ab = (float*)(part + (size_t)N * chunks * 2);
+    float* gpart = ab + (size_t)N * 2;
+    hipLaunchKernelGGL(ln_partial, dim3(chunks, N), dim3(256), 0, cg_s(stream), x, dy, gamma, mean, part, D, C, chunks, 1);
+    CG_LAUNCH_CHECK("ln_partial(bwd)");
+    hipLaunchKernelGGL(ln_bwd_final, dim3(cg_div_up(N, 64)), dim3(64), 0, cg_s(stream), (const double*)part, ab, N, chunks);
+    CG_LAUNCH_CHECK("ln_bwd_final");
+    const size_t total = (size_t)N * D;
+    hipLaunchKernelGGL(ln_bwd_apply, dim3(ew_grid(total)), dim3(256), 0, cg_s(stream), dy, x, gamma, mean, stdv,
+                       (const float*)ab, dx, total, D, C, eps);
+    CG_LAUNCH_CHECK("ln_bwd_apply");
+    const int rows = N * HW;
+    const int rchunks = (rows + LN_ROWS - 1) / LN_ROWS;
+    hipLaunchKernelGGL(ln_dgamma_partial, dim3(cg_div_up(C, 64), rchunks), dim3(256), 0, cg_s(stream), dy, x, mean, stdv,
+                       gpart, rows, HW, C, LN_ROWS, eps);
+    CG_LAUNCH_CHECK("ln_dgamma_partial");
+    hipLaunchKernelGGL(ln_dgamma_final, dim3(cg_div_up(C, 256)), dim3(256), 0, cg_s(stream), (const float*)gpart, dgamma,
+                       dbeta, C, rchunks);
+    CG_LAUNCH_CHECK("ln_dgamma_final");
+    return CG_OK;
+}

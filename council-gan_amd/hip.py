@@ -1,0 +1,154 @@
+"""ctypes binding of include/council_gan_hip.h (the C-ABI boundary).
+
+There is NO fallback: if the shared library is missing, or a kernel is called without a GPU,
+this raises.  The product path never routes through PyTorch compute ops or the oracle."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int8, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcouncilgan_hip.so")
+
+ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "tanh": 3}
+MAX_TAPS = 64
+
+
+class ConvGeom(ctypes.Structure):
+    _fields_ = [("N", c_int32), ("H", c_int32), ("W", c_int32), ("C1", c_int32), ("C2", c_int32),
+                ("up", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("HoF", c_int32), ("WoF", c_int32),
+                ("osy", c_int32), ("osx", c_int32), ("ooy", c_int32), ("oox", c_int32),
+                ("stride", c_int32), ("T", c_int32), ("Cout", c_int32), ("act", c_int32),
+                ("dy", c_int8 * MAX_TAPS), ("dx", c_int8 * MAX_TAPS)]
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+_P = c_void_p
+_SIGS = {
+    "cg_last_error": (c_char_p, []),
+    "cg_version": (c_int, []),
+    "cg_conv2d_fwd": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P]),
+    "cg_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvGeom)]),
+    "cg_conv2d_wgrad": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "cg_weight_transpose": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int32), c_int, _P]),
+    "cg_act_fwd": (c_int, [_P, _P, c_size_t, c_int, _P]),
+    "cg_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
+    "cg_instnorm_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "cg_instnorm_stats": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
+    "cg_instnorm_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cg_instnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "cg_layernorm_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "cg_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
+    "cg_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
+    "cg_avgpool3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cg_avgpool3s2_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cg_upsample2x_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cg_upsample2x_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cg_global_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "cg_mask_blend_fwd": (c_int, [_P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
+    "cg_mask_blend_bwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
+    "cg_lsgan_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    "cg_lsgan_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "cg_focus_sums": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P]),
+    "cg_focus_total": (c_int, [_P, c_size_t, c_float, c_float, c_float, c_int, c_int, _P, _P]),
+    "cg_focus_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
+                             c_int, c_int, _P, _P]),
+    "cg_l1_mean_fwd": (c_int, [_P, _P, c_size_t, _P, _P]),
+    "cg_l1_mean_bwd": (c_int, [_P, _P, _P, c_size_t, _P, _P]),
+    "cg_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    "cg_fill": (c_int, [_P, c_size_t, c_float, _P]),
+    "cg_add": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "cg_axpby": (c_int, [c_float, _P, c_float, _P, c_size_t, _P]),
+    "cg_gather_rows": (c_int, [_P, _P, _P, c_int, c_size_t, _P]),
+    "cg_loss_match": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
+    "cg_ring_push": (c_int, [_P, c_int, c_int, _P, _P]),
+    "cg_prof_enable": (c_int, [c_int]),
+    "cg_prof_collect": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
+    "cg_prof_slot_name": (c_char_p, [c_int]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def load():
+    """Load the library (no GPU needed for this step) and declare every signature."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            "%s not found -- build it with `python council-gan_amd/build_hip.py` "
+            "(there is no CPU/PyTorch fallback for the hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HipError("%s failed (%d): %s" % (what, rc, load().cg_last_error().decode()))
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (None -> NULL).  Only fp32 CUDA tensors cross the ABI."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError("tensor on %s passed to a HIP kernel: the hot path has no CPU fallback" % t.device)
+    if t.dtype != torch.float32 and t.dtype != torch.int32 and t.dtype != torch.uint8:
+        raise HipError("unsupported dtype %s" % t.dtype)
+    return c_void_p(t.data_ptr())
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes):
+    """Per-device scratch owned by PyTorch's caching allocator; kernels on one stream are ordered,
+    so one buffer per device is shared by every op."""
+    dev = torch.cuda.current_device()
+    buf = _ws_cache.get(dev)
+    if buf is None or buf.numel() < nbytes:
+        n = max(int(nbytes), 1 << 20)
+        n = (n + (1 << 20) - 1) & ~((1 << 20) - 1)
+        buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+        _ws_cache[dev] = buf
+    return buf
+
+
+PROF_SLOTS = 32
+
+
+def prof_enable(on):
+    check(load().cg_prof_enable(int(bool(on))), "cg_prof_enable")
+
+
+def prof_collect():
+    """{kernel name: (launches, total ms, total algorithmic FLOPs)} since profiling was enabled."""
+    lib = load()
+    counts = (c_int64 * PROF_SLOTS)()
+    ms = (c_double * PROF_SLOTS)()
+    flops = (c_double * PROF_SLOTS)()
+    check(lib.cg_prof_collect(counts, ms, flops), "cg_prof_collect")
+    out = {}
+    for i in range(PROF_SLOTS):
+        if counts[i]:
+            out[lib.cg_prof_slot_name(i).decode()] = (int(counts[i]), float(ms[i]), float(flops[i]))
+    return out

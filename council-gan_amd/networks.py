@@ -1,0 +1,499 @@
+"""Networks of the Council-GAN hot path on the gfx950 kernels.
+
+Mirror of the reference's operator API (`/root/reference/networks.py`): the same class names,
+constructor arguments, attribute names and module tree, hence the same `state_dict` keys and
+shapes (published checkpoints load) and the same RNG consumption at construction (same seed ->
+same initial weights).  `nn.Conv2d` / `nn.Linear` objects are kept purely as parameter holders;
+their `forward` is never called -- every forward/backward goes through `ops` (HIP kernels).
+
+Layout: activations are channels_last (physical NHWC) fp32.  Fusions relative to the reference's
+module-by-module execution:
+  * ZeroPad2d is folded into the conv gather; bias + activation into the conv epilogue;
+  * InstanceNorm / AdaIN + activation + the ResBlock residual add run as one apply pass;
+  * nn.Upsample(2x nearest) is folded into the next conv's gather;
+  * torch.cat((x, x_input), 1) of the council discriminator is a two-source gather.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _unsupported(what):
+    raise NotImplementedError("%s is not reachable from the shipped configs (SURVEY.md 8a) and is not "
+                              "implemented on the HIP path" % what)
+
+
+##################################################################################
+# Normalization layers
+##################################################################################
+class AdaptiveInstanceNorm2d(nn.Module):
+    """networks.py:627-656.  weight/bias are assigned per forward by AdaINGen.assign_adain_params;
+    here they are column ranges of the MLP output, consumed in place by the AdaIN kernel."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features = num_features
+        self.eps = eps
+        self.momentum = momentum
+        self.weight = None
+        self.bias = None
+        self.params = None      # [B, P] MLP output
+        self.goff = self.boff = 0
+        # dummy buffers, kept for state_dict compatibility (networks.py:636-638)
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+
+    def forward(self, x, act='none', residual=None):
+        assert self.params is not None, "Please assign weight and bias before calling AdaIN!"
+        return ops.adain(x, self.params, self.goff, self.boff, act=act, residual=residual, eps=self.eps)
+
+    def __repr__(self):
+        return self.__class__.__name__ + '(' + str(self.num_features) + ')'
+
+
+class LayerNorm(nn.Module):
+    """networks.py:659-686."""
+
+    def __init__(self, num_features, eps=1e-5, affine=True):
+        super().__init__()
+        self.num_features = num_features
+        self.affine = affine
+        self.eps = eps
+        if self.affine:
+            self.gamma = nn.Parameter(torch.Tensor(num_features).uniform_())
+            self.beta = nn.Parameter(torch.zeros(num_features))
+
+    def forward(self, x):
+        if not self.affine:
+            _unsupported("LayerNorm(affine=False)")
+        if x.dim() != 4:
+            _unsupported("LayerNorm on non-4D input")
+        return ops.layer_norm(x, self.gamma, self.beta, self.eps)
+
+
+##################################################################################
+# Basic Blocks
+##################################################################################
+class Conv2dBlock(nn.Module):
+    """networks.py:463-521: ZeroPad2d -> Conv2d(bias) -> norm -> activation, as one or two kernels."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, stride,
+                 padding=0, norm='none', activation='relu', pad_type='zero'):
+        super().__init__()
+        self.use_bias = True
+        if pad_type != 'zero':
+            _unsupported("pad_type %r" % pad_type)
+        self.padding = padding
+        self.stride = stride
+        self.kernel_size = kernel_size
+        norm_dim = output_dim
+        self.norm_type = norm
+        if norm == 'in':
+            self.norm = nn.InstanceNorm2d(norm_dim)      # stateless marker (affine=False): no parameters
+        elif norm == 'ln':
+            self.norm = LayerNorm(norm_dim)
+        elif norm == 'adain':
+            self.norm = AdaptiveInstanceNorm2d(norm_dim)
+        elif norm == 'none':
+            self.norm = None
+        else:
+            _unsupported("norm %r" % norm)
+        if activation not in ('relu', 'lrelu', 'tanh', 'none'):
+            _unsupported("activation %r" % activation)
+        self.activation_type = activation
+        self.conv = nn.Conv2d(input_dim, output_dim, kernel_size, stride, bias=self.use_bias)
+
+    def forward(self, x, x2=None, upsample=False, residual=None):
+        act = self.activation_type
+        fused_act = act if self.norm is None else 'none'
+        y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, fused_act, x2=x2,
+                       upsample=upsample)
+        if self.norm_type == 'in':
+            y = ops.instance_norm(y, act=act, residual=residual, eps=self.norm.eps)
+        elif self.norm_type == 'adain':
+            y = self.norm(y, act=act, residual=residual)
+        elif self.norm_type == 'ln':
+            y = ops.activation(self.norm(y), act)
+            if residual is not None:
+                y = y + residual
+        elif residual is not None:
+            y = y + residual
+        return y
+
+
+class ResBlock(nn.Module):
+    """networks.py:448-461; `out += residual` is fused into the second norm's apply pass."""
+
+    def __init__(self, dim, norm='in', activation='relu', pad_type='zero'):
+        super().__init__()
+        model = []
+        model += [Conv2dBlock(dim, dim, 3, 1, 1, norm=norm, activation=activation, pad_type=pad_type)]
+        model += [Conv2dBlock(dim, dim, 3, 1, 1, norm=norm, activation='none', pad_type=pad_type)]
+        self.model = nn.Sequential(*model)
+
+    def forward(self, x):
+        return self.model[1](self.model[0](x), residual=x)
+
+
+class LinearBlock(nn.Module):
+    """networks.py:523-568 (norm 'none' only)."""
+
+    def __init__(self, input_dim, output_dim, norm='none', activation='relu'):
+        super().__init__()
+        self.fc = nn.Linear(input_dim, output_dim, bias=True)
+        if norm != 'none':
+            _unsupported("LinearBlock norm %r" % norm)
+        self.norm = None
+        if activation not in ('relu', 'lrelu', 'tanh', 'none'):
+            _unsupported("activation %r" % activation)
+        self.activation_type = activation
+
+    def forward(self, x):
+        return ops.linear(x, self.fc.weight, self.fc.bias, act=self.activation_type)
+
+
+##################################################################################
+# Sequential Models
+##################################################################################
+class ResBlocks(nn.Module):
+    def __init__(self, num_blocks, dim, norm='in', activation='relu', pad_type='zero'):
+        super().__init__()
+        self.model = nn.Sequential(*[ResBlock(dim, norm=norm, activation=activation, pad_type=pad_type)
+                                     for _ in range(num_blocks)])
+
+    def forward(self, x):
+        for blk in self.model:
+            x = blk(x)
+        return x
+
+
+class MLP(nn.Module):
+    """networks.py:432-443."""
+
+    def __init__(self, input_dim, output_dim, dim, n_blk, norm='none', activ='relu'):
+        super().__init__()
+        model = [LinearBlock(input_dim, dim, norm=norm, activation=activ)]
+        for _ in range(n_blk - 2):
+            model += [LinearBlock(dim, dim, norm=norm, activation=activ)]
+        model += [LinearBlock(dim, output_dim, norm='none', activation='none')]
+        self.model = nn.Sequential(*model)
+
+    def forward(self, x):
+        h = x.reshape(x.size(0), -1)
+        for blk in self.model:
+            h = blk(h)
+        return h
+
+
+##################################################################################
+# Encoder and Decoders
+##################################################################################
+class StyleEncoder(nn.Module):
+    """networks.py:337-353."""
+
+    def __init__(self, n_downsample, input_dim, dim, style_dim, norm, activ, pad_type):
+        super().__init__()
+        model = [Conv2dBlock(input_dim, dim, 7, 1, 3, norm=norm, activation=activ, pad_type=pad_type)]
+        for _ in range(2):
+            model += [Conv2dBlock(dim, 2 * dim, 4, 2, 1, norm=norm, activation=activ, pad_type=pad_type)]
+            dim *= 2
+        for _ in range(n_downsample - 2):
+            model += [Conv2dBlock(dim, dim, 4, 2, 1, norm=norm, activation=activ, pad_type=pad_type)]
+        model += [nn.AdaptiveAvgPool2d(1)]   # placeholder keeping the Sequential index; ops.global_avgpool runs
+        model += [nn.Conv2d(dim, style_dim, 1, 1, 0)]
+        self.model = nn.Sequential(*model)
+        self.output_dim = dim
+
+    def forward(self, x):
+        n = len(self.model)
+        for i in range(n - 2):
+            x = self.model[i](x)
+        x = ops.global_avgpool(x)
+        last = self.model[n - 1]
+        return ops.conv2d(x, last.weight, last.bias, 1, 0, 'none')
+
+
+class ContentEncoder(nn.Module):
+    """networks.py:355-369."""
+
+    def __init__(self, n_downsample, n_res, input_dim, dim, norm, activ, pad_type):
+        super().__init__()
+        model = [Conv2dBlock(input_dim, dim, 7, 1, 3, norm=norm, activation=activ, pad_type=pad_type)]
+        for _ in range(n_downsample):
+            model += [Conv2dBlock(dim, 2 * dim, 4, 2, 1, norm=norm, activation=activ, pad_type=pad_type)]
+            dim *= 2
+        model += [ResBlocks(n_res, dim, norm=norm, activation=activ, pad_type=pad_type)]
+        self.model = nn.Sequential(*model)
+        self.output_dim = dim
+
+    def forward(self, x):
+        for m in self.model:
+            x = m(x)
+        return x
+
+
+class Decoder_V2_atten(nn.Module):
+    """networks.py:374-415: AdaIN ResBlocks, 2x (upsample, conv-AdaIN-ReLU, conv-AdaIN-ReLU), three 1x1
+    convs, mask/blend head."""
+
+    def __init__(self, n_upsample, n_res, dim, output_dim, res_norm='adain', activ='relu', pad_type='zero',
+                 num_of_mask_dim_to_add=1):
+        super().__init__()
+        self.num_of_mask_dim_to_add = num_of_mask_dim_to_add
+        self.output_dim = output_dim
+        self.n_upsample = n_upsample
+        self.mask_s = []
+        model = [ResBlocks(n_res, dim, res_norm, activ, pad_type=pad_type)]
+        for _ in range(n_upsample):
+            model += [nn.Upsample(scale_factor=2)]      # placeholder: fused into the next conv's gather
+            model += [Conv2dBlock(dim, dim // 2, 3, 1, 1, norm='adain', activation=activ, pad_type=pad_type)]
+            dim //= 2
+            model += [Conv2dBlock(dim, dim, 3, 1, 1, norm='adain', activation=activ, pad_type=pad_type)]
+        model += [Conv2dBlock(dim, dim, 1, 1, 0, norm='none', activation=activ, pad_type=pad_type)]
+        model += [Conv2dBlock(dim, dim, 1, 1, 0, norm='none', activation=activ, pad_type=pad_type)]
+        model += [Conv2dBlock(dim, output_dim * num_of_mask_dim_to_add + num_of_mask_dim_to_add, 1, 1, 0,
+                              norm='none', activation='tanh', pad_type=pad_type)]
+        self.model = nn.Sequential(*model)
+
+    def forward(self, x, im_in, return_mask=False):
+        y = self.model[0](x)
+        i = 1
+        for _ in range(self.n_upsample):
+            y = self.model[i + 1](y, upsample=True)
+            y = self.model[i + 2](y)
+            i += 3
+        y = self.model[i](y)
+        y = self.model[i + 1](y)
+        new_x = self.model[i + 2](y)
+        new_im, self.mask_s = ops.mask_blend(new_x, im_in, self.output_dim, self.num_of_mask_dim_to_add)
+        if return_mask:
+            if self.mask_s.shape[1] != 3:            # networks.py:410-412 (host-side display helper)
+                k = self.mask_s.shape[1]
+                self.mask_s = (torch.sum(self.mask_s, 1).unsqueeze(1).repeat(1, 3, 1, 1) / k)
+            return new_im, self.mask_s
+        return new_im
+
+
+##################################################################################
+# Generator
+##################################################################################
+class AdaINGen(nn.Module):
+    """networks.py:223-330."""
+
+    def __init__(self, input_dim, params, cuda_device='cuda:0'):
+        super().__init__()
+        dim = params['dim']
+        style_dim = params['style_dim']
+        self.n_downsample = params['n_downsample']
+        n_res = params['n_res']
+        self.activ = params['activ']
+        pad_type = params['pad_type']
+        mlp_dim = params['mlp_dim']
+        self.do_my_style = params['do_my_style']
+        self.cuda_device = cuda_device
+        if self.do_my_style:
+            _unsupported("gen.do_my_style")
+        self.enc_style = StyleEncoder(4, input_dim, dim, style_dim, norm='none', activ=self.activ, pad_type=pad_type)
+        self.enc_content = ContentEncoder(self.n_downsample, n_res, input_dim, dim, 'in', self.activ,
+                                          pad_type=pad_type)
+        self.dec = Decoder_V2_atten(self.n_downsample, n_res, self.enc_content.output_dim, input_dim,
+                                    res_norm='adain', activ=self.activ, pad_type=pad_type,
+                                    num_of_mask_dim_to_add=params['num_of_mask_dim_to_add'])
+        self.mlp = MLP(input_dim=style_dim, output_dim=self.get_num_adain_params(self.dec), dim=mlp_dim, n_blk=3,
+                       norm='none', activ=self.activ)
+        # column ranges of the MLP output per AdaIN layer, in modules() order (networks.py:303-312):
+        # [start, start+C) -> bias ("mean"), [start+C, start+2C) -> weight ("std")
+        start = 0
+        for m in self.dec.modules():
+            if m.__class__.__name__ == "AdaptiveInstanceNorm2d":
+                m.boff, m.goff = start, start + m.num_features
+                start += 2 * m.num_features
+
+    def forward(self, images, style, return_mask=False):
+        content, _ = self.encode(images)
+        return self.decode(content, style, images, return_mask=return_mask)
+
+    def encode_content(self, images):
+        """Content code only.  The hot path never uses the style code (the
+        StyleEncoder output is discarded when recon_s_w = recon_x_w = 0), so the trainer calls this."""
+        return self.enc_content(images)
+
+    def encode(self, images):
+        # networks.py:278-283
+        style_fake = self.enc_style(images)
+        content = self.enc_content(images)
+        return content, style_fake
+
+    def decode(self, content, style, images, return_mask=False):
+        # networks.py:285-301
+        adain_params = self.mlp(style)
+        self.assign_adain_params(adain_params, self.dec)
+        return self.dec(content, images, return_mask)
+
+    def assign_adain_params(self, adain_params, model):
+        for m in model.modules():
+            if m.__class__.__name__ == "AdaptiveInstanceNorm2d":
+                m.params = adain_params
+                m.bias = adain_params[:, m.boff:m.boff + m.num_features]        # views, no copy
+                m.weight = adain_params[:, m.goff:m.goff + m.num_features]
+
+    def get_num_adain_params(self, model):
+        return sum(2 * m.num_features for m in model.modules() if m.__class__.__name__ == "AdaptiveInstanceNorm2d")
+
+
+##################################################################################
+# Discriminators
+##################################################################################
+class _LossVectors:
+    """Per-sample LSGAN target / weight vectors on the device, cached by value."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, tgt, wt, device):
+        key = (tuple(tgt), tuple(wt), str(device))
+        v = self._cache.get(key)
+        if v is None:
+            v = (torch.tensor(tgt, dtype=torch.float32, device=device),
+                 torch.tensor(wt, dtype=torch.float32, device=device))
+            if len(self._cache) > 256:
+                self._cache.clear()
+            self._cache[key] = v
+        return v
+
+
+class MsImageDis(nn.Module):
+    """Multi-scale PatchGAN discriminator, networks.py:17-110 (LSGAN)."""
+
+    def __init__(self, input_dim, params, cuda_device='cuda:0'):
+        super().__init__()
+        self.n_layer = params['n_layer']
+        self.gan_type = params['gan_type']
+        self.dim = params['dim']
+        self.norm = params['norm']
+        self.activ = params['activ']
+        self.num_scales = params['num_scales']
+        self.pad_type = params['pad_type']
+        self.cuda_device = cuda_device
+        self.input_dim = input_dim
+        if self.gan_type != 'lsgan':
+            _unsupported("gan_type %r" % self.gan_type)
+        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)  # placeholder
+        self.cnns = nn.ModuleList()
+        for _ in range(self.num_scales):
+            self.cnns.append(self._make_net())
+        self._vec = _LossVectors()
+
+    def _make_net(self):
+        dim = self.dim
+        cnn_x = [Conv2dBlock(self.input_dim, dim, 4, 2, 1, norm='none', activation=self.activ, pad_type=self.pad_type)]
+        for _ in range(self.n_layer - 1):
+            cnn_x += [Conv2dBlock(dim, dim * 2, 4, 2, 1, norm=self.norm, activation=self.activ, pad_type=self.pad_type)]
+            dim *= 2
+        cnn_x += [nn.Conv2d(dim, 1, 1, 1, 0)]
+        return nn.Sequential(*cnn_x)
+
+    def forward(self, x):
+        outputs = []
+        for si, model in enumerate(self.cnns):
+            y = x
+            for blk in list(model)[:-1]:
+                y = blk(y)
+            last = model[len(model) - 1]
+            outputs.append(ops.conv2d(y, last.weight, last.bias, 1, 0, 'none'))
+            if si + 1 < len(self.cnns):
+                x = ops.avgpool3s2(x)
+        return outputs
+
+    def calc_dis_loss(self, input_fake, input_real, weight=1.0):
+        """networks.py:56-82.  Fake and real run as ONE batch (the net has no cross-sample op)."""
+        b = input_fake.shape[0]
+        outs = self.forward(torch.cat((input_fake, input_real), 0))
+        tgt, wt = self._vec.get([0.0] * b + [1.0] * input_real.shape[0], [weight] * (b + input_real.shape[0]),
+                                input_fake.device)
+        return ops.lsgan_loss(outs, tgt, wt, b)
+
+    def calc_gen_loss(self, input_fake, input_real=None, weight=1.0):
+        """networks.py:84-110."""
+        b = input_fake.shape[0]
+        outs = self.forward(input_fake)
+        tgt, wt = self._vec.get([1.0] * b, [weight] * b, input_fake.device)
+        return ops.lsgan_loss(outs, tgt, wt, b)
+
+
+class MsImageDisCouncil(nn.Module):
+    """Council (conditional) discriminator, networks.py:116-215: the candidate image and the input image
+    enter the first 3x3 conv as a two-source gather instead of a materialised 6-channel concat."""
+
+    def __init__(self, input_dim, params, cuda_device='cuda:0'):
+        super().__init__()
+        self.n_layer = params['n_layer']
+        self.gan_type = params['gan_type']
+        self.dim = params['dim']
+        self.norm = params['norm']
+        self.activ = params['activ']
+        self.num_scales = params['num_scales']
+        self.pad_type = params['pad_type']
+        self.cuda_device = cuda_device
+        self.input_dim = input_dim
+        if self.gan_type != 'lsgan':
+            _unsupported("gan_type %r" % self.gan_type)
+        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)  # placeholder
+        self.cnns = nn.ModuleList()
+        for _ in range(self.num_scales):
+            self.cnns.append(self._make_net())
+        self._vec = _LossVectors()
+
+    def _make_net(self):
+        dim = self.dim
+        cnn_x = [Conv2dBlock(2 * self.input_dim, dim, 3, 1, 1, norm='none', activation=self.activ,
+                             pad_type=self.pad_type)]
+        for _ in range(self.n_layer - 1):
+            cnn_x += [Conv2dBlock(dim, dim * 2, 4, 2, 1, norm=self.norm, activation=self.activ, pad_type=self.pad_type)]
+            dim *= 2
+        cnn_x += [nn.Conv2d(dim, dim, 1, 1, 0)]
+        cnn_x += [nn.Conv2d(dim, 1, 1, 1, 0)]
+        return nn.Sequential(*cnn_x)
+
+    def forward(self, x, x_input):
+        outputs = []
+        for si, model in enumerate(self.cnns):
+            blocks = list(model)
+            y = blocks[0](x, x2=x_input)
+            for blk in blocks[1:-2]:
+                y = blk(y)
+            y = ops.conv2d(y, blocks[-2].weight, blocks[-2].bias, 1, 0, 'none')
+            outputs.append(ops.conv2d(y, blocks[-1].weight, blocks[-1].bias, 1, 0, 'none'))
+            if si + 1 < len(self.cnns):
+                x = ops.avgpool3s2(x)
+                x_input = ops.avgpool3s2(x_input)
+        return outputs
+
+    def calc_dis_loss(self, input_fake, input_real, input, weight=1.0):
+        """networks.py:158-186 (reference signature)."""
+        return self.calc_dis_loss_multi(input_fake, [input_real], [1.0], input, fake_weight=1.0, weight=weight)
+
+    def calc_dis_loss_multi(self, input_fake, reals, real_weights, input, fake_weight, weight=1.0):
+        """sum_k [ mean(D(fake)^2) + mean((D(real_k) - 1)^2) ] with repeated terms folded into weights:
+        the reference re-runs the identical fake pass for every colleague pick (trainer_council.py:
+        862-874); here fake and the distinct colleagues' images run once, as one batch."""
+        b = input_fake.shape[0]
+        groups = 1 + len(reals)
+        x = torch.cat([input_fake] + list(reals), 0)
+        x_in = torch.cat([input] * groups, 0) if groups > 1 else input
+        outs = self.forward(x, x_in)
+        tgt = [0.0] * b
+        wt = [weight * fake_weight] * b
+        for r, rw in zip(reals, real_weights):
+            tgt += [1.0] * r.shape[0]
+            wt += [weight * rw] * r.shape[0]
+        tgt, wt = self._vec.get(tgt, wt, input_fake.device)
+        return ops.lsgan_loss(outs, tgt, wt, b)
+
+    def calc_gen_loss(self, input_fake, input, input_real=None, weight=1.0):
+        """networks.py:188-215."""
+        b = input_fake.shape[0]
+        outs = self.forward(input_fake, input)
+        tgt, wt = self._vec.get([1.0] * b, [weight] * b, input_fake.device)
+        return ops.lsgan_loss(outs, tgt, wt, b)

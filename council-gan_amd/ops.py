@@ -1,0 +1,559 @@
+"""Operators of the Council-GAN hot path: HIP forward + HIP backward behind torch.autograd.
+
+PyTorch's role here is plumbing only: device memory (caching allocator), the stream, and the
+autograd tape that sequences the backward kernels.  All arithmetic runs in the gfx950 library
+through the C-ABI (`hip.py`).  Activations are logical NCHW tensors with `channels_last`
+strides (= physical NHWC); conv weights are logical OIHW with `channels_last` strides
+(= physical [O][KH][KW][I]), so state_dict shapes stay those of the reference.
+
+Parameter gradients: when a parameter carries a `_cg_grad` buffer (a view into the owning
+optimizer's flat gradient buffer, see optim.py) the backward kernels accumulate straight into it
+and autograd receives None for that input; otherwise the gradient is returned normally.
+"""
+import ctypes
+from ctypes import byref, c_void_p
+
+import torch
+
+from . import hip
+from .hip import ACT, ConvGeom, check, ptr, stream, workspace
+
+CL = torch.channels_last
+
+
+def nhwc(t):
+    return t if t is None else t.contiguous(memory_format=CL)
+
+
+def empty_nhwc(n, c, h, w, like):
+    return torch.empty((n, c, h, w), dtype=torch.float32, device=like.device, memory_format=CL)
+
+
+def _lib():
+    return hip.load()
+
+
+def _off(t, elems):
+    return c_void_p(t.data_ptr() + 4 * elems)
+
+
+# ------------------------------------------------------------------------------------------
+# convolution geometry
+# ------------------------------------------------------------------------------------------
+def fwd_geom(N, H, W, C1, C2, up, KH, KW, stride, pad, Cout, act):
+    """Forward pass of ZeroPad2d(pad) -> Conv2d(KHxKW, stride) (networks.py:515-516) on an input that
+    is optionally read through a nearest 2x upsample (networks.py:385)."""
+    g = ConvGeom()
+    Hl, Wl = H << up, W << up
+    Ho = (Hl + 2 * pad - KH) // stride + 1
+    Wo = (Wl + 2 * pad - KW) // stride + 1
+    if KH * KW > hip.MAX_TAPS:
+        raise ValueError("kernel %dx%d has more than %d taps" % (KH, KW, hip.MAX_TAPS))
+    g.N, g.H, g.W, g.C1, g.C2, g.up = N, H, W, C1, C2, up
+    g.Ho, g.Wo, g.HoF, g.WoF = Ho, Wo, Ho, Wo
+    g.osy = g.osx = 1
+    g.ooy = g.oox = 0
+    g.stride, g.T, g.Cout, g.act = stride, KH * KW, Cout, act
+    for kh in range(KH):
+        for kw in range(KW):
+            g.dy[kh * KW + kw] = kh - pad
+            g.dx[kh * KW + kw] = kw - pad
+    return g
+
+
+def dgrad_classes(Hl, Wl, KH, KW, stride, pad):
+    """Data-gradient of a strided conv = one stride-1 pass per output-parity class (ph, pw):
+    dx[s*oy+ph] = sum over taps kh with (ph+pad-kh) % s == 0 of dz[oy + (ph+pad-kh)/s] * W[kh]."""
+    out = []
+    for ph in range(stride):
+        for pw in range(stride):
+            taps = []
+            for kh in range(KH):
+                if (ph + pad - kh) % stride:
+                    continue
+                for kw in range(KW):
+                    if (pw + pad - kw) % stride:
+                        continue
+                    taps.append((kh * KW + kw, (ph + pad - kh) // stride, (pw + pad - kw) // stride))
+            Hc = (Hl - ph + stride - 1) // stride
+            Wc = (Wl - pw + stride - 1) // stride
+            if Hc > 0 and Wc > 0:
+                out.append((ph, pw, Hc, Wc, taps))
+    return out
+
+
+def conv_dgrad(dz, w, Cin_total, ci0, nci, KH, KW, stride, pad, H, W, up):
+    """dx (w.r.t. channels [ci0, ci0+nci) of the conv input) from dz [N,Cout,Ho,Wo]; runs the forward
+    implicit-GEMM kernel on dz with re-laid-out weights."""
+    lib = _lib()
+    N, Cout, Ho, Wo = dz.shape
+    Hl, Wl = H << up, W << up
+    dxl = empty_nhwc(N, nci, Hl, Wl, dz)
+    T = KH * KW
+    for ph, pw, Hc, Wc, taps in dgrad_classes(Hl, Wl, KH, KW, stride, pad):
+        if not taps:
+            raise NotImplementedError("stride > kernel size leaves input positions without taps")
+        Tc = len(taps)
+        wt = torch.empty(nci * Tc * Cout, dtype=torch.float32, device=dz.device)
+        tapmap = (ctypes.c_int32 * Tc)(*[t for t, _, _ in taps])
+        check(lib.cg_weight_transpose(ptr(w), ptr(wt), Cout, T, Cin_total, ci0, nci, tapmap, Tc, stream()),
+              "cg_weight_transpose")
+        g = ConvGeom()
+        g.N, g.H, g.W, g.C1, g.C2, g.up = N, Ho, Wo, Cout, 0, 0
+        g.Ho, g.Wo, g.HoF, g.WoF = Hc, Wc, Hl, Wl
+        g.osy = g.osx = stride
+        g.ooy, g.oox = ph, pw
+        g.stride, g.T, g.Cout, g.act = 1, Tc, nci, 0
+        for i, (_, dy, dx) in enumerate(taps):
+            g.dy[i], g.dx[i] = dy, dx
+        check(lib.cg_conv2d_fwd(byref(g), ptr(dz), None, ptr(wt), None, ptr(dxl), stream()), "cg_conv2d_fwd(dgrad)")
+    if not up:
+        return dxl
+    dx = empty_nhwc(N, nci, H, W, dz)
+    check(lib.cg_upsample2x_bwd(ptr(dxl), ptr(dx), N, H, W, nci, stream()), "cg_upsample2x_bwd")
+    return dx
+
+
+class _Conv2d(torch.autograd.Function):
+    """act(conv2d(zero_pad(x (++ x2)), weight) + bias); networks.py:515-521 without the norm."""
+
+    @staticmethod
+    def forward(ctx, x, x2, weight, bias, wgrad_buf, bgrad_buf, stride, pad, act, up):
+        lib = _lib()
+        x, x2, w = nhwc(x), nhwc(x2), nhwc(weight)
+        N, C1, H, W = x.shape
+        C2 = x2.shape[1] if x2 is not None else 0
+        Cout, Ct, KH, KW = w.shape
+        if Ct != C1 + C2:
+            raise ValueError("conv weight expects %d input channels, got %d" % (Ct, C1 + C2))
+        if x2 is not None and tuple(x2.shape[0:1] + x2.shape[2:]) != (N, H, W):
+            raise ValueError("concat sources must agree in N, H, W")
+        g = fwd_geom(N, H, W, C1, C2, int(up), KH, KW, stride, pad, Cout, act)
+        y = empty_nhwc(N, Cout, g.Ho, g.Wo, x)
+        check(lib.cg_conv2d_fwd(byref(g), ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), stream()), "cg_conv2d_fwd")
+        ctx.save_for_backward(x, x2, w, y if act else None)
+        ctx.g, ctx.meta = g, (KH, KW, stride, pad, act, int(up), bias is not None)
+        ctx.wgrad_buf, ctx.bgrad_buf = wgrad_buf, bgrad_buf
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        x, x2, w, y = ctx.saved_tensors
+        KH, KW, stride, pad, act, up, has_bias = ctx.meta
+        g = ctx.g
+        dy = nhwc(dy)
+        if act:
+            dz = torch.empty_like(dy)
+            check(lib.cg_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), act, stream()), "cg_act_bwd")
+        else:
+            dz = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3]):
+            ws = workspace(lib.cg_conv2d_wgrad_workspace(byref(g)))
+            if ctx.wgrad_buf is not None:
+                # accumulate straight into the optimizer's flat gradient buffer (optim.py)
+                dw_t, acc = ctx.wgrad_buf, 1
+                db_t = ctx.bgrad_buf if has_bias else None
+                dw_t._cg_touched = True
+                if db_t is not None:
+                    db_t._cg_touched = True
+            else:
+                dw_t, acc = torch.empty_like(w), 0
+                db_t = torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if has_bias else None
+                dw, db = dw_t, db_t
+            check(lib.cg_conv2d_wgrad(byref(g), ptr(x), ptr(x2), ptr(dz), ptr(dw_t), ptr(db_t), acc, ptr(ws),
+                                      ws.numel(), stream()), "cg_conv2d_wgrad")
+        if ctx.needs_input_grad[0]:
+            N, C1, H, W = x.shape
+            dx = conv_dgrad(dz, w, w.shape[1], 0, C1, KH, KW, stride, pad, H, W, up)
+        dx2 = None
+        if x2 is not None and ctx.needs_input_grad[1]:
+            N, C1, H, W = x.shape
+            dx2 = conv_dgrad(dz, w, w.shape[1], C1, x2.shape[1], KH, KW, stride, pad, H, W, up)
+        return dx, dx2, dw, db, None, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=False):
+    """Functional conv.  `weight` may be an nn.Parameter managed by a flat optimizer buffer."""
+    return _Conv2d.apply(x, x2, weight, bias, getattr(weight, "_cg_grad", None),
+                         getattr(bias, "_cg_grad", None) if bias is not None else None,
+                         int(stride), int(pad), ACT[act], bool(upsample))
+
+
+def linear(x, weight, bias=None, act="none"):
+    """nn.Linear (networks.py:531) as a 1x1 conv on an [N, C, 1, 1] tensor."""
+    n = x.shape[0]
+    w4 = weight.view(weight.shape[0], weight.shape[1], 1, 1)
+    y = _Conv2d.apply(x.reshape(n, -1, 1, 1), None, w4, bias, getattr(weight, "_cg_grad", None),
+                      getattr(bias, "_cg_grad", None) if bias is not None else None, 1, 0, ACT[act], False)
+    return y.reshape(n, -1)
+
+
+# ------------------------------------------------------------------------------------------
+# instance norm / AdaIN (+ activation + residual)
+# ------------------------------------------------------------------------------------------
+class _InstNormAct(torch.autograd.Function):
+    """y = act(IN(x) * gamma + beta) + residual.  gamma/beta are columns [goff, goff+C) / [boff, boff+C)
+    of `params` ([N, P], the MLP output, networks.py:303-312) or absent (plain nn.InstanceNorm2d)."""
+
+    @staticmethod
+    def forward(ctx, x, params, goff, boff, residual, act, eps):
+        lib = _lib()
+        x, residual = nhwc(x), nhwc(residual)
+        N, C, H, W = x.shape
+        HW = H * W
+        mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = workspace(lib.cg_instnorm_workspace(N, HW, C))
+        check(lib.cg_instnorm_stats(ptr(x), N, HW, C, eps, ptr(mean), ptr(rstd), ptr(ws), ws.numel(), stream()),
+              "cg_instnorm_stats")
+        y = torch.empty_like(x)
+        if params is not None:
+            params = params.contiguous()
+            if params.shape[0] != N or goff + C > params.shape[1] or boff + C > params.shape[1]:
+                raise ValueError("AdaIN parameter slice out of range")
+            gp, bp, gs = _off(params, goff), _off(params, boff), params.shape[1]
+        else:
+            gp, bp, gs = None, None, C
+        check(lib.cg_instnorm_apply(ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(residual), ptr(y), N, HW, C, act,
+                                    stream()), "cg_instnorm_apply")
+        ctx.save_for_backward(x, mean, rstd, params)
+        ctx.meta = (goff, boff, act, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        x, mean, rstd, params = ctx.saved_tensors
+        goff, boff, act, has_res = ctx.meta
+        dy = nhwc(dy)
+        N, C, H, W = x.shape
+        HW = H * W
+        dx = torch.empty_like(x)
+        ws = workspace(lib.cg_instnorm_workspace(N, HW, C))
+        dparams = None
+        if params is not None:
+            gp, bp, gs = _off(params, goff), _off(params, boff), params.shape[1]
+            if ctx.needs_input_grad[1]:
+                dparams = torch.empty_like(params)
+                check(lib.cg_fill(ptr(dparams), dparams.numel(), 0.0, stream()), "cg_fill")
+                dgp, dbp = _off(dparams, goff), _off(dparams, boff)
+            else:
+                dgp = dbp = None
+        else:
+            gp = bp = dgp = dbp = None
+            gs = C
+        check(lib.cg_instnorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(dx), dgp, dbp, N, HW, C, act,
+                                  ptr(ws), ws.numel(), stream()), "cg_instnorm_bwd")
+        return dx, dparams, None, None, (dy if has_res else None), None, None
+
+
+def instance_norm(x, act="none", residual=None, eps=1e-5):
+    return _InstNormAct.apply(x, None, 0, 0, residual, ACT[act], float(eps))
+
+
+def adain(x, params, goff, boff, act="none", residual=None, eps=1e-5):
+    return _InstNormAct.apply(x, params, int(goff), int(boff), residual, ACT[act], float(eps))
+
+
+class _Activation(torch.autograd.Function):
+    """Standalone activation (only the LayerNorm path needs it; convs and IN/AdaIN fuse theirs)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        lib = _lib()
+        x = x.contiguous(memory_format=CL) if x.dim() == 4 else x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.cg_act_fwd(ptr(x), ptr(y), x.numel(), act, stream()), "cg_act_fwd")
+        ctx.save_for_backward(y)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=CL) if dy.dim() == 4 else dy.contiguous()
+        dz = torch.empty_like(y)
+        check(lib.cg_act_bwd(ptr(dy), ptr(y), ptr(dz), y.numel(), ctx.act, stream()), "cg_act_bwd")
+        return dz, None
+
+
+def activation(x, act):
+    return x if ACT[act] == 0 else _Activation.apply(x, ACT[act])
+
+
+class _LayerNorm(torch.autograd.Function):
+    """networks.py:670-686."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        lib = _lib()
+        x = nhwc(x)
+        N, C, H, W = x.shape
+        ctx.bufs = (getattr(gamma, "_cg_grad", None), getattr(beta, "_cg_grad", None))
+        y = torch.empty_like(x)
+        mean = torch.empty(N, dtype=torch.float32, device=x.device)
+        std = torch.empty_like(mean)
+        ws = workspace(lib.cg_layernorm_workspace(N, H * W, C))
+        check(lib.cg_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(std), N, H * W, C, eps, ptr(ws),
+                                   ws.numel(), stream()), "cg_layernorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, std)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        x, gamma, mean, std = ctx.saved_tensors
+        dy = nhwc(dy)
+        N, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty_like(gamma)
+        db = torch.empty_like(gamma)
+        ws = workspace(lib.cg_layernorm_workspace(N, H * W, C))
+        check(lib.cg_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(std), ptr(dx), ptr(dg), ptr(db), N, H * W,
+                                   C, ctx.eps, ptr(ws), ws.numel(), stream()), "cg_layernorm_bwd")
+        gbuf, bbuf = ctx.bufs
+        if gbuf is not None and bbuf is not None:
+            check(lib.cg_axpby(1.0, ptr(dg), 1.0, ptr(gbuf), C, stream()), "cg_axpby")
+            check(lib.cg_axpby(1.0, ptr(db), 1.0, ptr(bbuf), C, stream()), "cg_axpby")
+            gbuf._cg_touched = bbuf._cg_touched = True
+            dg = db = None
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, float(eps))
+
+
+# ------------------------------------------------------------------------------------------
+# resampling
+# ------------------------------------------------------------------------------------------
+class _AvgPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib()
+        x = nhwc(x)
+        N, C, H, W = x.shape
+        y = empty_nhwc(N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, x)
+        check(lib.cg_avgpool3s2_fwd(ptr(x), ptr(y), N, H, W, C, stream()), "cg_avgpool3s2_fwd")
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        N, C, H, W = ctx.shape
+        dy = nhwc(dy)
+        dx = empty_nhwc(N, C, H, W, dy)
+        check(lib.cg_avgpool3s2_bwd(ptr(dy), ptr(dx), N, H, W, C, stream()), "cg_avgpool3s2_bwd")
+        return dx
+
+
+def avgpool3s2(x):
+    return _AvgPool3s2.apply(x)
+
+
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib()
+        x = nhwc(x)
+        N, C, H, W = x.shape
+        y = empty_nhwc(N, C, 2 * H, 2 * W, x)
+        check(lib.cg_upsample2x_fwd(ptr(x), ptr(y), N, H, W, C, stream()), "cg_upsample2x_fwd")
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        N, C, H, W = ctx.shape
+        dy = nhwc(dy)
+        dx = empty_nhwc(N, C, H, W, dy)
+        check(lib.cg_upsample2x_bwd(ptr(dy), ptr(dx), N, H, W, C, stream()), "cg_upsample2x_bwd")
+        return dx
+
+
+def upsample2x(x):
+    return _Upsample2x.apply(x)
+
+
+def global_avgpool(x):
+    """nn.AdaptiveAvgPool2d(1), networks.py:347.  Forward only: the style code never receives a
+    gradient on the shipped configs (recon_s_w = 0)."""
+    lib = _lib()
+    if x.requires_grad and torch.is_grad_enabled():
+        x = x.detach()
+    x = nhwc(x)
+    N, C, H, W = x.shape
+    y = empty_nhwc(N, C, 1, 1, x)
+    check(lib.cg_global_avgpool_fwd(ptr(x), ptr(y), N, H * W, C, stream()), "cg_global_avgpool_fwd")
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# mask / blend head (networks.py:398-407)
+# ------------------------------------------------------------------------------------------
+class _MaskBlend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, new_x, im_in, od, k):
+        lib = _lib()
+        new_x, im_in = nhwc(new_x), nhwc(im_in)
+        N, CH, H, W = new_x.shape
+        if CH != od * k + k or im_in.shape[1] != od:
+            raise ValueError("mask/blend head expects %d channels" % (od * k + k))
+        im_out = empty_nhwc(N, od, H, W, new_x)
+        mask = empty_nhwc(N, k, H, W, new_x)
+        check(lib.cg_mask_blend_fwd(ptr(new_x), ptr(im_in), ptr(im_out), ptr(mask), N * H * W, od, k, stream()),
+              "cg_mask_blend_fwd")
+        ctx.save_for_backward(new_x, im_in)
+        ctx.meta = (od, k)
+        ctx.set_materialize_grads(False)
+        return im_out, mask
+
+    @staticmethod
+    def backward(ctx, d_im, d_mask):
+        lib = _lib()
+        new_x, im_in = ctx.saved_tensors
+        od, k = ctx.meta
+        N, CH, H, W = new_x.shape
+        if d_im is None:
+            d_im = empty_nhwc(N, od, H, W, new_x)
+            check(lib.cg_fill(ptr(d_im), d_im.numel(), 0.0, stream()), "cg_fill")
+        d_im, d_mask = nhwc(d_im), nhwc(d_mask)
+        d_new = torch.empty_like(new_x)
+        check(lib.cg_mask_blend_bwd(ptr(new_x), ptr(im_in), ptr(d_im), ptr(d_mask), ptr(d_new), N * H * W, od, k,
+                                    stream()), "cg_mask_blend_bwd")
+        return d_new, None, None, None
+
+
+def mask_blend(new_x, im_in, od, k):
+    return _MaskBlend.apply(new_x, im_in, int(od), int(k))
+
+
+# ------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------
+class _Lsgan(torch.autograd.Function):
+    """sum over scales of  sum_s wt[s] * mean_hw (o - tgt[s])^2 / group   (networks.py:64,90,166,194).
+    tgt / wt are device vectors with one entry per sample of the (batched) discriminator input."""
+
+    @staticmethod
+    def forward(ctx, tgt, wt, group, *outs):
+        lib = _lib()
+        loss = torch.empty(1, dtype=torch.float32, device=tgt.device)
+        outs = [o.contiguous() for o in outs]
+        for i, o in enumerate(outs):
+            nb = o.shape[0]
+            hw = o.numel() // nb
+            check(lib.cg_lsgan_fwd(ptr(o), ptr(tgt), ptr(wt), nb, hw, group, ptr(loss), int(i > 0), stream()),
+                  "cg_lsgan_fwd")
+        ctx.save_for_backward(tgt, wt, *outs)
+        ctx.group = group
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        tgt, wt, *outs = ctx.saved_tensors
+        g = g.contiguous()
+        grads = []
+        for o in outs:
+            nb = o.shape[0]
+            hw = o.numel() // nb
+            d = torch.empty_like(o)
+            check(lib.cg_lsgan_bwd(ptr(o), ptr(tgt), ptr(wt), ptr(g), nb, hw, ctx.group, ptr(d), stream()),
+                  "cg_lsgan_bwd")
+            grads.append(d)
+        return (None, None, None) + tuple(grads)
+
+
+def lsgan_loss(outs, tgt, wt, group):
+    return _Lsgan.apply(tgt, wt, int(group), *outs)
+
+
+class _FocusLoss(torch.autograd.Function):
+    """w_zo * mask_zero_one + w_total * mask_small + w_tv * TV   (trainer_council.py:230-250).
+    Returns (total, parts[3]) -- parts = the three unweighted criteria, for logging."""
+
+    @staticmethod
+    def forward(ctx, mask, center, eps, w_zo, w_total, w_tv, use_abs, use_square):
+        lib = _lib()
+        mask = nhwc(mask)
+        N, k, H, W = mask.shape
+        sums = torch.empty(3, dtype=torch.float32, device=mask.device)
+        out = torch.empty(4, dtype=torch.float32, device=mask.device)
+        check(lib.cg_focus_sums(ptr(mask), N, H, W, k, center, eps, ptr(sums), stream()), "cg_focus_sums")
+        check(lib.cg_focus_total(ptr(sums), mask.numel(), w_zo, w_total, w_tv, int(use_abs), int(use_square), ptr(out),
+                                 stream()), "cg_focus_total")
+        ctx.save_for_backward(mask, sums)
+        ctx.meta = (center, eps, w_zo, w_total, w_tv, int(use_abs), int(use_square))
+        parts = out[1:]
+        ctx.mark_non_differentiable(parts)
+        return out[0], parts
+
+    @staticmethod
+    def backward(ctx, g, _gparts):
+        lib = _lib()
+        mask, sums = ctx.saved_tensors
+        center, eps, w_zo, w_total, w_tv, use_abs, use_square = ctx.meta
+        N, k, H, W = mask.shape
+        g = g.contiguous()
+        d = torch.empty_like(mask)
+        check(lib.cg_focus_bwd(ptr(mask), ptr(sums), ptr(g), N, H, W, k, center, eps, w_zo, w_total, w_tv, use_abs,
+                               use_square, ptr(d), stream()), "cg_focus_bwd")
+        return d, None, None, None, None, None, None, None
+
+
+def focus_loss(mask, center, eps, w_zo, w_total, w_tv, use_abs, use_square):
+    return _FocusLoss.apply(mask, float(center), float(eps), float(w_zo), float(w_total), float(w_tv),
+                            bool(use_abs), bool(use_square))
+
+
+class _L1Mean(torch.autograd.Function):
+    """mean |a - b| (trainer_council.py:207-208); gradient flows to `a` only."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib()
+        if a.shape != b.shape:
+            raise ValueError("l1_mean: shape mismatch")
+        fmt = CL if a.dim() == 4 else torch.contiguous_format
+        a, b = a.contiguous(memory_format=fmt), b.contiguous(memory_format=fmt)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        check(lib.cg_l1_mean_fwd(ptr(a), ptr(b), a.numel(), ptr(loss), stream()), "cg_l1_mean_fwd")
+        ctx.save_for_backward(a, b)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        a, b = ctx.saved_tensors
+        da = torch.empty_like(a)
+        check(lib.cg_l1_mean_bwd(ptr(a), ptr(b), ptr(g.contiguous()), a.numel(), ptr(da), stream()), "cg_l1_mean_bwd")
+        return da, None
+
+
+def l1_mean(a, b):
+    return _L1Mean.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------
+# utilities
+# ------------------------------------------------------------------------------------------
+def fill_(t, value):
+    check(_lib().cg_fill(ptr(t), t.numel(), float(value), stream()), "cg_fill")
+    return t
+
+
+def gather_rows(src, idx_dev, nidx):
+    """out[i] = src[idx[i]] along dim 0 (colleague pick after the council exchange)."""
+    row = src[0].numel()
+    out = torch.empty((nidx,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    if src.dim() == 4 and src.is_contiguous(memory_format=CL):
+        out = torch.empty((nidx,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device, memory_format=CL)
+    check(_lib().cg_gather_rows(ptr(src), ptr(idx_dev), ptr(out), nidx, row, stream()), "cg_gather_rows")
+    return out

@@ -1,0 +1,150 @@
+"""Flat-buffer Adam: torch.optim.Adam semantics (trainer_council.py:170-179 -- lr, betas,
+L2 weight_decay, eps 1e-8, no amsgrad) executed by ONE HIP kernel per contiguous run of
+parameters that received a gradient.
+
+All parameters of one optimizer live in one flat fp32 buffer (data / grad / exp_avg / exp_avg_sq);
+`p.data` and `p.grad` become views into it (conv weights keep their logical OIHW shape with
+channels_last strides, so state_dict shapes are unchanged).  Backward kernels accumulate straight
+into the grad views (ops.py), `zero_grad()` is a single fill, `step()` a single kernel.
+
+torch.optim.Adam skips parameters whose `.grad is None` (no decay, no step count): that is how
+the reference leaves `enc_style` untouched in gen_update.  Here a parameter counts
+as "without gradient" until a backward kernel has written to its grad view since the last
+zero_grad (the `_cg_touched` flag set in ops.py)."""
+import torch
+
+from . import hip
+from .hip import check, ptr, stream
+
+
+def _phys_view(flat, off, shape):
+    """View of flat[off: off+n] with logical `shape`; 4-D tensors get channels_last strides."""
+    n = 1
+    for s in shape:
+        n *= s
+    seg = flat[off:off + n]
+    if len(shape) == 4:
+        o, i, kh, kw = shape
+        return seg.view(o, kh, kw, i).permute(0, 3, 1, 2)
+    return seg.view(shape)
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        params = [p for p in params if p.requires_grad]
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False)
+        super().__init__(params, defaults)
+        self._params = params
+        self._flat = None
+        self._steps = [0] * len(params)
+
+    # -- flat storage ---------------------------------------------------------------------
+    def materialize(self, device):
+        """Move every parameter into the flat buffer on `device` (idempotent per device)."""
+        device = torch.device(device)
+        if self._flat is not None and self._flat["data"].device == device:
+            return
+        sizes = [p.numel() for p in self._params]
+        total = sum(sizes)
+        old = self._flat
+        data = torch.empty(total, dtype=torch.float32, device=device)
+        grad = torch.zeros(total, dtype=torch.float32, device=device)
+        m = torch.zeros(total, dtype=torch.float32, device=device)
+        v = torch.zeros(total, dtype=torch.float32, device=device)
+        if old is not None:
+            m.copy_(old["m"])
+            v.copy_(old["v"])
+        offs, off = [], 0
+        for p, n in zip(self._params, sizes):
+            view = _phys_view(data, off, tuple(p.shape))
+            view.copy_(p.data)
+            p.data = view
+            g = _phys_view(grad, off, tuple(p.shape))
+            g._cg_touched = False
+            p._cg_grad = g
+            p.grad = g
+            offs.append(off)
+            off += n
+        self._flat = dict(data=data, grad=grad, m=m, v=v, offs=offs, sizes=sizes)
+
+    @property
+    def flat(self):
+        if self._flat is None:
+            raise RuntimeError("FlatAdam.materialize(device) has not been called")
+        return self._flat
+
+    # -- torch.optim API -------------------------------------------------------------------
+    def zero_grad(self, set_to_none=False):
+        f = self.flat
+        if f["grad"].is_cuda:
+            check(hip.load().cg_fill(ptr(f["grad"]), f["grad"].numel(), 0.0, stream()), "cg_fill")
+        else:
+            f["grad"].zero_()
+        for p in self._params:
+            p._cg_grad._cg_touched = False
+            p.grad = p._cg_grad
+
+    def touched_runs(self):
+        """Maximal runs [i0, i1) of consecutive parameters that received a gradient and share a step count."""
+        runs, i, n = [], 0, len(self._params)
+        while i < n:
+            if not self._params[i]._cg_grad._cg_touched:
+                i += 1
+                continue
+            j = i
+            while j + 1 < n and self._params[j + 1]._cg_grad._cg_touched and self._steps[j + 1] == self._steps[i]:
+                j += 1
+            runs.append((i, j + 1))
+            i = j + 1
+        return runs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        f = self.flat
+        grp = self.param_groups[0]
+        b1, b2 = grp["betas"]
+        lib = hip.load()
+        for i0, i1 in self.touched_runs():
+            off = f["offs"][i0]
+            n = f["offs"][i1 - 1] + f["sizes"][i1 - 1] - off
+            step = self._steps[i0] + 1
+            sl = slice(off, off + n)
+            check(lib.cg_adam_step(ptr(f["data"][sl]), ptr(f["grad"][sl]), ptr(f["m"][sl]), ptr(f["v"][sl]), n,
+                                   float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
+                                   float(grp["weight_decay"]), step, stream()), "cg_adam_step")
+            for k in range(i0, i1):
+                self._steps[k] = step
+
+    # -- checkpoint compatibility with torch.optim.Adam (trainer_council.py:989-992) --------------
+    def state_dict(self):
+        f = self.flat
+        state = {}
+        for i, p in enumerate(self._params):
+            if self._steps[i] == 0:
+                continue
+            off = f["offs"][i]
+            state[i] = {"step": torch.tensor(float(self._steps[i])),
+                        "exp_avg": _phys_view(f["m"], off, tuple(p.shape)).clone(),
+                        "exp_avg_sq": _phys_view(f["v"], off, tuple(p.shape)).clone()}
+        groups = []
+        for g in self.param_groups:
+            gg = {k: v for k, v in g.items() if k != "params"}
+            gg["params"] = list(range(len(self._params)))
+            groups.append(gg)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        f = self.flat
+        for i, p in enumerate(self._params):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            off = f["offs"][i]
+            if st is None:
+                self._steps[i] = 0
+                continue
+            self._steps[i] = int(float(st["step"]))
+            _phys_view(f["m"], off, tuple(p.shape)).copy_(st["exp_avg"])
+            _phys_view(f["v"], off, tuple(p.shape)).copy_(st["exp_avg_sq"])
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            for k, v in sg.items():
+                if k != "params":
+                    g[k] = v

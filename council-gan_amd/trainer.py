@@ -1,0 +1,564 @@
+"""Council_Trainer on the gfx950 kernels -- drop-in for `/root/reference/trainer_council.py`.
+
+Same constructor, same `dis_update / dis_council_update / gen_update / sample / save / resume /
+update_learning_rate` signatures, same member lists (`gen_a2b_s[i]` ...), same reflected logging
+attributes, same host-RNG draws in the same order, so the reference `train.py`
+runs unchanged on top of it.
+
+What is restructured (results unchanged, SURVEY.md 8d "redundancy the build may remove"):
+  * the generator runs without an autograd tape in the two discriminator updates (the reference
+    builds the graph and detaches, trainer_council.py:760-769, 837-872);
+  * the style encoder is skipped (its output is discarded on every shipped config);
+  * fake + real go through D as one batch; in the council-D update the own image and the DISTINCT
+    colleagues' images go through once with per-sample loss weights (the reference repeats the
+    identical fake pass per pick, :862-874);
+  * D / council-D weight gradients are not computed in gen_update (the reference accumulates and
+    then zeroes them);
+  * loss matching (:518-524, 576-586) runs on device rings: no host sync inside the step.
+
+Multi-GPU: one process per GPU, council members sharded across ranks (member m lives on rank
+m // members_per_rank); everything host-side (batch, style noise, Python RNG picks) is replicated;
+the ONLY collective on the data path is one all-gather of the generated images in
+`dis_council_update` (the cross-member dependency at trainer_council.py:853-856, 872-874).
+"""
+import os
+import random
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip, ops
+from .hip import check, ptr, stream
+from .networks import AdaINGen, MsImageDis, MsImageDisCouncil
+from .optim import FlatAdam
+from .parallel import CouncilShard
+from .utils import get_model_list, get_scheduler, weights_init
+
+
+def _check_supported(hp):
+    for k in ('recon_x_w', 'recon_s_w', 'recon_c_w', 'recon_x_cyc_w', 'vgg_w', 'abs_beginning_end', 'council_abs_w'):
+        if hp.get(k, 0) != 0:
+            raise NotImplementedError("%s != 0 is outside the shipped-config hot path (SURVEY.md 8a R2)" % k)
+    if hp['gen']['useRandomDis'] or hp['dis']['useRandomGen']:
+        raise NotImplementedError("useRandomDis / useRandomGen break member sharding and are False in every "
+                                  "shipped config (SURVEY.md 8e)")
+    if hp['dis']['do_Dis_only_gray']:
+        raise NotImplementedError("dis.do_Dis_only_gray is False in every shipped config")
+    if hp['focus_loss']['do_w_loss_matching_focus']:
+        raise NotImplementedError("focus_loss.do_w_loss_matching_focus is False in every shipped config")
+
+
+class Council_Trainer(nn.Module):
+    def __init__(self, hyperparameters, cuda_device='cuda:0', shard=None):
+        super().__init__()
+        hp = hyperparameters
+        _check_supported(hp)
+        lr = hp['lr']
+        self.council_size = hp['council']['council_size']
+        self.council_size_conf = self.council_size
+        self.do_dis_council = hp['council_w'] != 0
+        self.do_ads_council_loss = hp['council_abs_w'] != 0
+        self.numberOfCouncil_dis_relative_iteration_conf = hp['council']['numberOfCouncil_dis_relative_iteration']
+        self.discriminetro_less_style_by_conf = hp['council']['discriminetro_less_style_by']
+        self.cuda_device = cuda_device
+        self.shard = shard if shard is not None else CouncilShard.from_env(self.council_size)
+
+        # every variable ending in '_conf' is displayed in the tensorboard logs (trainer_council.py:37-68)
+        self.recon_x_w_conf = hp['recon_x_w']
+        self.recon_c_w_conf = hp['recon_c_w']
+        self.recon_s_w_conf = hp['recon_s_w']
+        self.recon_x_cyc_w_conf = hp['recon_x_cyc_w']
+        self.gan_w_conf = hp['gan_w']
+        self.vgg_w_conf = hp['vgg_w']
+        self.abs_beginning_end_w_conf = hp['abs_beginning_end']
+        self.flipOnOff_On_iteration_conf = hp['council']['flipOnOff_On_iteration']
+        self.flipOnOff_Off_iteration_conf = hp['council']['flipOnOff_start_with']   # sic, :46-47
+        self.council_abs_w_conf = hp['council_abs_w']
+        self.council_w_conf = hp['council_w']
+        self.council_start_at_iter_conf = hp['council']['council_start_at_iter']
+        self.focus_loss_start_at_iter_conf = hp['focus_loss']['focus_loss_start_at_iter']
+        self.mask_zero_or_one_w_conf = hp['mask_zero_or_one_w']
+        self.mask_zero_or_one_center_conf = hp['focus_loss']['mask_zero_or_one_center']
+        self.mask_zero_or_one_epsilon_conf = hp['focus_loss']['mask_zero_or_one_epsilon']
+        self.mask_total_w_conf = hp['mask_total_w']
+        self.mask_tv_w_conf = hp['mask_tv_w']
+        self.batch_size_conf = hp['batch_size']
+        self.do_w_loss_matching = hp['do_w_loss_matching']
+        self.do_w_loss_matching_focus = hp['focus_loss']['do_w_loss_matching_focus']
+        self.los_matching_hist_size_conf = hp['loss_matching_hist_size']
+        self.do_a2b_conf = hp['do_a2b']
+        self.do_b2a_conf = hp['do_b2a']
+        self.w_match_b2a_conf = 1
+        self.w_match_a2b_conf = 1
+        self.do_council_loss = None
+        self._dirs = [d for d in ('a2b', 'b2a') if hp['do_' + d]]
+
+        # networks, built on the host in the reference's order (same RNG stream), trainer_council.py:100-133
+        gen_a2b, dis_a2b, disc_a2b, gen_b2a, dis_b2a, disc_b2a = [], [], [], [], [], []
+        for _ in range(self.council_size):
+            if self.do_a2b_conf:
+                gen_a2b.append(AdaINGen(hp['input_dim_a'], hp['gen'], cuda_device=cuda_device))
+                dis_a2b.append(MsImageDis(hp['input_dim_a'], hp['dis'], cuda_device=cuda_device))
+                if self.do_dis_council:
+                    disc_a2b.append(MsImageDisCouncil(hp['input_dim_a'], hp['dis'], cuda_device=cuda_device))
+            if self.do_b2a_conf:
+                gen_b2a.append(AdaINGen(hp['input_dim_b'], hp['gen'], cuda_device=cuda_device))
+                dis_b2a.append(MsImageDis(hp['input_dim_b'], hp['dis'], cuda_device=cuda_device))
+                if self.do_dis_council:
+                    disc_b2a.append(MsImageDisCouncil(hp['input_dim_b'], hp['dis'], cuda_device=cuda_device))
+        self.instancenorm = nn.InstanceNorm2d(512, affine=False)     # :121 (VGG loss helper, unused; kept for order)
+        self.style_dim = hp['gen']['style_dim']
+        self.gen_a2b_s, self.gen_b2a_s, self.dis_a2b_s, self.dis_b2a_s = [], [], [], []
+        if self.do_dis_council:
+            self.dis_council_a2b_s, self.dis_council_b2a_s = [], []
+        if self.do_a2b_conf:
+            self.gen_a2b_s = nn.ModuleList(gen_a2b)
+            self.dis_a2b_s = nn.ModuleList(dis_a2b)
+            if self.do_dis_council:
+                self.dis_council_a2b_s = nn.ModuleList(disc_a2b)
+        if self.do_b2a_conf:
+            self.gen_b2a_s = nn.ModuleList(gen_b2a)
+            self.dis_b2a_s = nn.ModuleList(dis_b2a)
+            if self.do_dis_council:
+                self.dis_council_b2a_s = nn.ModuleList(disc_b2a)
+
+        # fixed sampling noise (:135-138) -- drawn here to keep the RNG stream aligned
+        display_size = int(hp['display_size'])
+        self.s_a = torch.randn(display_size, self.style_dim, 1, 1)
+        self.s_b = torch.randn(display_size, self.style_dim, 1, 1)
+
+        # optimizers (:139-183): one flat-buffer Adam per member and network kind
+        beta1, beta2, wd = hp['beta1'], hp['beta2'], hp['weight_decay']
+        self.dis_opt_s, self.gen_opt_s, self.dis_scheduler_s, self.gen_scheduler_s = [], [], [], []
+        if self.do_dis_council:
+            self.dis_council_opt_s, self.dis_council_scheduler_s = [], []
+        for i in range(self.council_size):
+            dis_p, gen_p, disc_p = [], [], []
+            if self.do_a2b_conf:
+                dis_p += list(self.dis_a2b_s[i].parameters())
+                gen_p += list(self.gen_a2b_s[i].parameters())
+                if self.do_dis_council:
+                    disc_p += list(self.dis_council_a2b_s[i].parameters())
+            if self.do_b2a_conf:
+                dis_p += list(self.dis_b2a_s[i].parameters())
+                gen_p += list(self.gen_b2a_s[i].parameters())
+                if self.do_dis_council:
+                    disc_p += list(self.dis_council_b2a_s[i].parameters())
+            self.dis_opt_s.append(FlatAdam(dis_p, lr=lr, betas=(beta1, beta2), weight_decay=wd))
+            self.gen_opt_s.append(FlatAdam(gen_p, lr=lr, betas=(beta1, beta2), weight_decay=wd))
+            if self.do_dis_council:
+                self.dis_council_opt_s.append(FlatAdam(disc_p, lr=lr, betas=(beta1, beta2), weight_decay=wd))
+            self.dis_scheduler_s.append(get_scheduler(self.dis_opt_s[i], hp))
+            self.gen_scheduler_s.append(get_scheduler(self.gen_opt_s[i], hp))
+            if self.do_dis_council:
+                self.dis_council_scheduler_s.append(get_scheduler(self.dis_council_opt_s[i], hp))
+
+        # weight initialisation, same call sequence as :185-197
+        self.apply(weights_init(hp['init']))
+        for i in range(self.council_size):
+            if self.do_a2b_conf:
+                self.gen_a2b_s[i].apply(weights_init(hp['init']))
+                self.dis_a2b_s[i].apply(weights_init('gaussian'))
+                if self.do_dis_council:
+                    self.dis_council_a2b_s[i].apply(weights_init('gaussian'))
+            if self.do_b2a_conf:
+                self.gen_b2a_s[i].apply(weights_init(hp['init']))
+                self.dis_b2a_s[i].apply(weights_init('gaussian'))
+                if self.do_dis_council:
+                    self.dis_council_b2a_s[i].apply(weights_init('gaussian'))
+        self.vgg = None
+
+        # loss-matching history (:71-92): device rings, filled with ones, one push per gen_update
+        self._ring_n = int(self.los_matching_hist_size_conf)
+        self._ring_pos = {d: [0] * self.council_size for d in self._dirs}
+        self._ring_pos_c = {d: [0] * self.council_size for d in self._dirs}
+        self._rings = None
+        self._device = None
+
+    # ------------------------------------------------------------------------------------
+    # device placement
+    # ------------------------------------------------------------------------------------
+    def _nets(self, kind, d):
+        return getattr(self, {'gen': 'gen_%s_s', 'dis': 'dis_%s_s', 'disc': 'dis_council_%s_s'}[kind] % d)
+
+    def cuda(self, device=None):
+        dev = torch.device(device if device is not None else self.cuda_device)
+        if dev.type != 'cuda':
+            raise hip.HipError("Council_Trainer runs on an MI355X only (got device %s): there is no CPU fallback" % dev)
+        torch.cuda.set_device(dev)
+        hip.load()
+        self.s_a, self.s_b = self.s_a.to(dev), self.s_b.to(dev)
+        for i in self.shard.local:       # non-local members stay on the host, untouched
+            for d in self._dirs:
+                for kind in ('gen', 'dis') + (('disc',) if self.do_dis_council else ()):
+                    net = self._nets(kind, d)[i]
+                    for b in net.buffers():
+                        b.data = b.data.to(dev)
+            self.gen_opt_s[i].materialize(dev)
+            self.dis_opt_s[i].materialize(dev)
+            if self.do_dis_council:
+                self.dis_council_opt_s[i].materialize(dev)
+        self._rings = {d: {i: (torch.ones(self._ring_n, device=dev), torch.ones(self._ring_n, device=dev),
+                               torch.ones(1, device=dev))
+                           for i in self.shard.local} for d in self._dirs}
+        self._device = dev
+        return self
+
+    def to(self, *args, **kwargs):
+        dev = args[0] if args else kwargs.get('device')
+        return self.cuda(dev)
+
+    def _ready(self):
+        if self._device is None:
+            self.cuda(self.cuda_device)
+
+    def _img(self, x):
+        return x.to(self._device, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+
+    def _noise(self, n):
+        # CPU RNG then upload, exactly as the reference (trainer_council.py:284-285,741,744,807-809)
+        return torch.randn(n, self.style_dim, 1, 1)
+
+    # ------------------------------------------------------------------------------------
+    # schedules (host integers), trainer_council.py:541-555, 784-801
+    # ------------------------------------------------------------------------------------
+    @staticmethod
+    def _flip_state(hp):
+        c = hp['council']
+        cycle = c['flipOnOff_On_iteration'] + c['flipOnOff_Off_iteration']
+        cur = hp['iteration'] % cycle
+        start = c['flipOnOff_On_iteration'] if c['flipOnOff_start_with'] else c['flipOnOff_Off_iteration']
+        return c['flipOnOff_start_with'] if cur < start else (not c['flipOnOff_start_with'])
+
+    # ------------------------------------------------------------------------------------
+    # dis_update, trainer_council.py:735-780
+    # ------------------------------------------------------------------------------------
+    def dis_update(self, x_a=None, x_b=None, hyperparameters=None):
+        hp = hyperparameters
+        self._ready()
+        x = {'a2b': self._img(x_a), 'b2a': self._img(x_b)}      # source image per direction
+        tgt = {'a2b': x['b2a'], 'b2a': x['a2b']}                 # real image of the target domain
+        for i in self.shard.local:
+            self.dis_opt_s[i].zero_grad()
+        s = {}
+        if self.do_a2b_conf:
+            s['a2b'] = self._noise(x_b.size(0)).to(self._device)
+            self.loss_dis_a2b_s = [0] * self.council_size
+        if self.do_b2a_conf:
+            s['b2a'] = self._noise(x_a.size(0)).to(self._device)
+            self.loss_dis_b2a_s = [0] * self.council_size
+        self.loss_dis_total_s = [0] * self.council_size
+        for i in self.shard.local:
+            total = None
+            for d in self._dirs:
+                gen = self._nets('gen', d)[i]
+                with torch.no_grad():
+                    x_fake = gen.decode(gen.encode_content(x[d]), s[d], x[d])
+                # :775-777 -- only the a2b term is scaled by gan_w (reference quirk, kept); the scale is
+                # folded into the per-sample loss weights
+                w = float(hp['gan_w']) if d == 'a2b' else 1.0
+                l = self._nets('dis', d)[i].calc_dis_loss(x_fake, tgt[d], weight=w)
+                getattr(self, 'loss_dis_%s_s' % d)[i] = l.detach() / w if w != 1.0 else l.detach()
+                total = l if total is None else total + l
+            self.loss_dis_total_s[i] = total.detach()
+            total.backward()
+            self.dis_opt_s[i].step()
+
+    # ------------------------------------------------------------------------------------
+    # dis_council_update, trainer_council.py:782-883
+    # ------------------------------------------------------------------------------------
+    def dis_council_update(self, x_a=None, x_b=None, hyperparameters=None):
+        hp = hyperparameters
+        c = hp['council']
+        if self.council_size <= 1 or c['numberOfCouncil_dis_relative_iteration'] == 0:
+            print('no council discriminetor is needed (council size <= 1 or numberOfCouncil_dis_relative_iteration == 0)')
+            return
+        self.do_council_loss = self._flip_state(hp)
+        if not c['flipOnOff']:
+            self.do_council_loss = c['flipOnOff_start_with']
+        if not self.do_council_loss or hp['council_w'] == 0 or hp['iteration'] < c['council_start_at_iter']:
+            return
+        self._ready()
+        x = {'a2b': self._img(x_a), 'b2a': self._img(x_b)}
+        for i in self.shard.local:
+            self.dis_council_opt_s[i].zero_grad()
+        s, s_less = {}, {}
+        if self.do_b2a_conf:                       # s_a is drawn first here (:806-809)
+            s['b2a'] = self._noise(x_a.size(0))
+        if self.do_a2b_conf:
+            s['a2b'] = self._noise(x_b.size(0))
+        less = c['discriminetro_less_style_by']
+        for d in self._dirs:
+            if less != 0:
+                s_less[d] = (s[d] * less).to(self._device)
+            s[d] = s[d].to(self._device)
+        n_rel = c['numberOfCouncil_dis_relative_iteration']
+
+        x_full = {d: {} for d in self._dirs}
+        x_cmp_local = {d: [] for d in self._dirs}
+        with torch.no_grad():
+            for i in self.shard.local:
+                for d in self._dirs:
+                    gen = self._nets('gen', d)[i]
+                    content = gen.encode_content(x[d])
+                    x_full[d][i] = gen.decode(content, s[d], x[d])
+                    x_cmp_local[d].append(gen.decode(content, s_less[d], x[d]) if less != 0 else x_full[d][i])
+        # the ONE cross-member exchange (trainer_council.py:853-856): every member's comparison image
+        x_cmp = {d: self.shard.exchange(x_cmp_local[d]) for d in self._dirs}
+
+        self.loss_dis_council_a2b_s = [0] * self.council_size
+        self.loss_dis_council_b2a_s = [0] * self.council_size
+        self.loss_dis_council_total_s = [0] * self.council_size
+        scale = float(hp['council_w']) / float(n_rel)                      # :878-880
+        for i in range(self.council_size):
+            picks = self.draw_colleagues(i, self.council_size, n_rel)     # every rank replays every member's draws
+            if i not in self.shard.local:
+                continue
+            uniq = sorted(set(picks))
+            mult = [float(picks.count(j)) for j in uniq]
+            total = None
+            for d in self._dirs:
+                l = self._nets('disc', d)[i].calc_dis_loss_multi(
+                    x_full[d][i], [x_cmp[d][j] for j in uniq], mult, x[d], fake_weight=float(len(picks)), weight=scale)
+                getattr(self, 'loss_dis_council_%s_s' % d)[i] = l.detach() / scale
+                total = l if total is None else total + l
+            self.loss_dis_council_total_s[i] = total.detach()
+            total.backward()
+            self.dis_council_opt_s[i].step()
+
+    @staticmethod
+    def draw_colleagues(i, council_size, n_rel):
+        """trainer_council.py:861-868 (Python global RNG, identical call sequence)."""
+        picks = []
+        pool = list(range(0, i)) + list(range(i + 1, council_size))
+        for k in range(n_rel):
+            if k == council_size:
+                break
+            if len(pool) == 0:
+                pool = list(range(0, i)) + list(range(i + 1, council_size))
+            j = random.choice(pool)
+            pool.remove(j)
+            picks.append(j)
+        return picks
+
+    # ------------------------------------------------------------------------------------
+    # gen_update, trainer_council.py:280-634
+    # ------------------------------------------------------------------------------------
+    def gen_update(self, x_a, x_b, hyperparameters, iterations=0):
+        hp = hyperparameters
+        self.hyperparameters = hp
+        self._ready()
+        lib = hip.load()
+        x = {'a2b': self._img(x_a), 'b2a': self._img(x_b)}
+        for i in self.shard.local:
+            self.gen_opt_s[i].zero_grad()
+        s_a = self._noise(x_a.size(0)).to(self._device)     # both drawn, s_a first (:284-285)
+        s_b = self._noise(x_b.size(0)).to(self._device)
+        s = {'a2b': s_b, 'b2a': s_a}
+        fl = hp['focus_loss']
+        focus_live = hp['iteration'] > fl['focus_loss_start_at_iter']
+        self.council_w_conf = hp['council_w'] if hp['iteration'] > hp['council']['council_start_at_iter'] else 0
+        self.mask_zero_or_one_w_conf = hp['mask_zero_or_one_w'] if focus_live else 0
+        self.mask_total_w_conf = hp['mask_total_w'] if focus_live else 0
+        self.mask_tv_w_conf = hp['mask_tv_w'] if focus_live else 0
+        focus_on = focus_live and (hp['mask_zero_or_one_w'] != 0 or hp['mask_total_w'] != 0)      # :390
+
+        self.do_council_loss = self._flip_state(hp)                                                # :541-555
+        if not hp['council']['flipOnOff']:
+            self.do_council_loss = True
+        if hp['iteration'] < hp['council']['council_start_at_iter']:
+            self.do_council_loss = False
+        council_on = (hp['council_w'] != 0) and self.do_council_loss and self.council_size > 1 and self.do_dis_council
+
+        C = self.council_size
+        ab = {'a2b': 'ab', 'b2a': 'ba'}
+        self.loss_gen_total_s = [0] * C
+        for d in self._dirs:
+            setattr(self, 'loss_gen_adv_%s_s' % d, [0] * C)
+            setattr(self, 'loss_gen_mask_zero_one_%s_s' % ab[d], [0] * C if focus_on and hp['mask_zero_or_one_w'] != 0 else [])
+            setattr(self, 'loss_gen_mask_total_%s_s' % ab[d], [0] * C)
+            setattr(self, 'loss_gen_mask_TV_%s_s' % ab[d], [0] * C)
+            setattr(self, 'council_loss_%s_s' % ab[d], [0] * C)
+        for d in ('a2b', 'b2a'):
+            if d not in self._dirs:
+                setattr(self, 'loss_gen_adv_%s_s' % d, [0] * C)
+
+        frozen = []
+        for i in self.shard.local:       # no weight gradients for D / council-D in this update
+            for d in self._dirs:
+                for kind in ('dis',) + (('disc',) if self.do_dis_council else ()):
+                    for p in self._nets(kind, d)[i].parameters():
+                        if p.requires_grad:
+                            p.requires_grad_(False)
+                            frozen.append(p)
+        try:
+            for i in self.shard.local:
+                total = None
+                for d in self._dirs:
+                    gen = self._nets('gen', d)[i]
+                    x_fake = gen.decode(gen.encode_content(x[d]), s[d], x[d])
+                    mask = gen.dec.mask_s
+                    terms = []
+                    if focus_on:                                                   # :390-451
+                        ftot, parts = ops.focus_loss(mask, fl['mask_zero_or_one_center'], fl['mask_zero_or_one_epsilon'],
+                                                     hp['mask_zero_or_one_w'], hp['mask_total_w'], hp['mask_tv_w'],
+                                                     fl['mask_small_use_abs'], fl['mask_small_use_square'])
+                        terms.append(ftot)
+                        if hp['mask_zero_or_one_w'] != 0:
+                            getattr(self, 'loss_gen_mask_zero_one_%s_s' % ab[d])[i] = parts[0]
+                        if hp['mask_total_w'] != 0:
+                            getattr(self, 'loss_gen_mask_total_%s_s' % ab[d])[i] = parts[1]
+                        if hp['mask_tv_w'] != 0:
+                            getattr(self, 'loss_gen_mask_TV_%s_s' % ab[d])[i] = parts[2]
+                    if hp['gan_w'] != 0:                                           # :498-529
+                        adv = self._nets('dis', d)[i].calc_gen_loss(x_fake)
+                        getattr(self, 'loss_gen_adv_%s_s' % d)[i] = adv.detach()
+                        ring_g, ring_c, w_dev = self._rings[d][i]
+                        if self.do_w_loss_matching:
+                            check(lib.cg_ring_push(ptr(ring_g), self._ring_n, self._ring_pos[d][i], ptr(adv.detach()),
+                                                   stream()), "cg_ring_push")
+                            self._ring_pos[d][i] += 1
+                        terms.append(adv * float(hp['gan_w']))
+                    if council_on:                                                 # :558-624
+                        lc = self._nets('disc', d)[i].calc_gen_loss(x_fake, x[d])
+                        if self.do_w_loss_matching:
+                            ring_g, ring_c, w_dev = self._rings[d][i]
+                            check(lib.cg_loss_match(ptr(ring_g), ptr(ring_c), self._ring_n, self._ring_pos_c[d][i],
+                                                    ptr(lc.detach()), ptr(w_dev), stream()), "cg_loss_match")
+                            self._ring_pos_c[d][i] += 1
+                            setattr(self, 'w_match_%s_conf' % d, w_dev[0])
+                            lc = lc * w_dev[0]
+                        lc = lc * float(hp['council_w'])
+                        getattr(self, 'council_loss_%s_s' % ab[d])[i] = lc.detach()
+                        terms.append(lc)
+                    for t in terms:
+                        total = t if total is None else total + t
+                self.loss_gen_total_s[i] = total.detach()
+                total.backward()
+                self.gen_opt_s[i].step()
+        finally:
+            for p in frozen:
+                p.requires_grad_(True)
+
+    # ------------------------------------------------------------------------------------
+    # forward-only paths, trainer_council.py:252-278, 643-733
+    # ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample(self, x_a=None, x_b=None, s_a=None, s_b=None, council_member_to_sample_vec=None, return_mask=True):
+        self._ready()
+        self.eval()
+        out = {}
+        members = range(self.council_size) if council_member_to_sample_vec is None else council_member_to_sample_vec
+        for d, xin, s_fixed in (('a2b', x_a, s_b if s_b is not None else self.s_b),
+                                ('b2a', x_b, s_a if s_a is not None else self.s_a)):
+            if d not in self._dirs:
+                continue
+            xin = self._img(xin)
+            s1 = s_fixed.to(self._device)
+            s2 = self._noise(xin.size(0)).to(self._device)
+            xs, recon, x1, x2, masks = [], [], [], [], []
+            for n in range(xin.size(0)):
+                for j in members:
+                    if j not in self.shard.local:
+                        continue
+                    gen = self._nets('gen', d)[j]
+                    xi = xin[n:n + 1]
+                    xs.append(xi)
+                    if not return_mask:
+                        content, s_fake = gen.encode(xi)
+                        recon.append(gen.decode(content, s_fake, xi))
+                        x1.append(gen.decode(content, s1[n:n + 1], xi))
+                    else:
+                        content = gen.encode_content(xi)
+                        im, m = gen.decode(content, s1[n:n + 1], xi, return_mask=True)
+                        x1.append(im)
+                        masks.append(m)
+                    x2.append(gen.decode(content, s2[n:n + 1], xi))
+            out[d] = (torch.cat(xs), torch.cat(masks) if return_mask else torch.cat(recon), torch.cat(x1), torch.cat(x2))
+        self.train()
+        none4 = (None, None, None, None)
+        return out.get('a2b', none4) + out.get('b2a', none4)
+
+    def forward(self, x_a, s_t=None, x_b=None, s_a=None, s_b=None):
+        """trainer_council.py:252-278 (its a2b branch references a non-existent self.gen_a2b; the
+        evident intent -- every member's translation -- is what runs here)."""
+        self._ready()
+        self.eval()
+        if s_t is not None:
+            s_a = s_b = s_t
+        res = {}
+        with torch.no_grad():
+            for d, xin, sd in (('a2b', x_a, s_b if s_b is not None else self.s_b),
+                               ('b2a', x_b if x_b is not None else x_a, s_a if s_a is not None else self.s_a)):
+                if d not in self._dirs:
+                    continue
+                xin = self._img(xin)
+                sd = sd.to(self._device)
+                res[d] = []
+                for i in self.shard.local:
+                    gen = self._nets('gen', d)[i]
+                    res[d].append(gen.decode(gen.encode_content(xin), sd, xin))
+        if self.do_a2b_conf and self.do_b2a_conf:
+            return res['a2b'], res['b2a']
+        return res['b2a'] if self.do_b2a_conf else res['a2b']
+
+    def update_learning_rate(self):
+        """trainer_council.py:885-896."""
+        for sch in self.dis_scheduler_s + self.gen_scheduler_s + (self.dis_council_scheduler_s if self.do_dis_council else []):
+            if sch is not None:
+                sch.step()
+
+    # ------------------------------------------------------------------------------------
+    # checkpoints, trainer_council.py:898-992 (file names / dict keys / tensor shapes unchanged;
+    # each rank writes and reads the files of its own members)
+    # ------------------------------------------------------------------------------------
+    def save(self, snapshot_dir, iterations):
+        self._ready()
+        for i in self.shard.local:
+            tag = '_%d_%08d.pt' % (i, iterations + 1)
+            for d in self._dirs:
+                torch.save({d: self._nets('gen', d)[i].state_dict()}, os.path.join(snapshot_dir, d + '_gen' + tag))
+                torch.save({d: self._nets('dis', d)[i].state_dict()}, os.path.join(snapshot_dir, d + '_dis' + tag))
+                if self.do_dis_council:
+                    torch.save({d: self._nets('disc', d)[i].state_dict()},
+                               os.path.join(snapshot_dir, d + '_dis_council' + tag))
+            opt = {'gen': self.gen_opt_s[i].state_dict(), 'dis': self.dis_opt_s[i].state_dict()}
+            if self.do_dis_council:
+                opt['dis_council'] = self.dis_council_opt_s[i].state_dict()
+            torch.save(opt, os.path.join(snapshot_dir, 'optimizer_%d.pt' % i))
+
+    def resume(self, checkpoint_dir, hyperparameters):
+        self._ready()
+        iterations = 0
+        dev = self._device
+        for i in self.shard.local:
+            for kind, key in (('gen', 'gen_%d' % i), ('dis', 'dis_%d' % i)) + \
+                    ((('disc', 'dis_council_%d' % i),) if self.do_dis_council else ()):
+                for d in self._dirs:
+                    name = get_model_list(checkpoint_dir, d + '_' + key)
+                    if name is None:
+                        warnings.warn('Failed to find %s checkpoint, did not load model' % key)
+                        continue
+                    print('loading: ' + name)
+                    self._nets(kind, d)[i].load_state_dict(torch.load(name, map_location=dev)[d])
+                    if kind == 'gen':
+                        iterations = int(name[-11:-3])
+            try:
+                sd = torch.load(os.path.join(checkpoint_dir, 'optimizer_%d.pt' % i), map_location=dev)
+                self.dis_opt_s[i].load_state_dict(sd['dis'])
+                self.gen_opt_s[i].load_state_dict(sd['gen'])
+                if self.do_dis_council:
+                    self.dis_council_opt_s[i].load_state_dict(sd['dis_council'])
+                self.dis_scheduler_s[i] = get_scheduler(self.dis_opt_s[i], hyperparameters, iterations)
+                self.gen_scheduler_s[i] = get_scheduler(self.gen_opt_s[i], hyperparameters, iterations)
+                if self.do_dis_council:
+                    self.dis_council_scheduler_s[i] = get_scheduler(self.dis_council_opt_s[i], hyperparameters, iterations)
+            except Exception:
+                warnings.warn('some optimizer FAILED to load ')
+        if iterations > 0:
+            print('Resume from iteration %d' % iterations)
+        else:
+            warnings.warn('FAILED TO RESUME STARTED FROM 0')
+        return iterations

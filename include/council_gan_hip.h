@@ -1,0 +1,195 @@
+/*
+ * council_gan_hip.h -- C-ABI of the MI355X (gfx950) Council-GAN hot-path library.
+ *
+ * This is the drop-in boundary.  The reference (Onr/Council-GAN) has no
+ * FFI of its own: all arithmetic of its hot path is dispatched from `networks.py` /
+ * `trainer_council.py` into PyTorch/ATen/cuDNN.  Each entry point below names the reference
+ * call site (file:line in /root/reference) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every tensor is fp32, physically NHWC (PyTorch `channels_last` strides over a logical
+ *     NCHW shape), dense; weights are physically [Cout][KH][KW][Cin] (channels_last OIHW);
+ *   - raw device pointers + explicit sizes, no torch types; the caller (PyTorch's caching
+ *     allocator) owns every buffer including workspaces;
+ *   - kernels are enqueued on `stream` and never synchronise; no global mutable state;
+ *   - return value 0 = ok, negative = error (see cg_last_error()); nothing throws across the ABI.
+ */
+#ifndef COUNCIL_GAN_HIP_H
+#define COUNCIL_GAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cg_stream_t; /* hipStream_t */
+
+#define CG_OK 0
+#define CG_ERR_ARG (-1)
+#define CG_ERR_LAUNCH (-2)
+#define CG_ERR_WORKSPACE (-3)
+
+#define CG_ACT_NONE 0
+#define CG_ACT_RELU 1
+#define CG_ACT_LRELU 2 /* LeakyReLU(0.2), networks.py:497 */
+#define CG_ACT_TANH 3
+
+#define CG_MAX_TAPS 64
+
+/* Geometry of one implicit-GEMM convolution pass (forward, data-gradient or weight-gradient).
+ * The input is gathered from up to two NHWC sources concatenated along C (networks.py:152
+ * torch.cat((x, x_input), 1)), optionally through a nearest 2x upsample (networks.py:385),
+ * at `T` taps; output position (oy, ox) of the enumerated Ho x Wo grid reads logical input
+ * (oy*stride + dy[t], ox*stride + dx[t]) -- zero outside (ZeroPad2d, networks.py:474) -- and
+ * is written to (oy*osy + ooy, ox*osx + oox) of an HoF x WoF output tensor.  Forward conv:
+ * dy[t] = kh - pad, osy = 1.  Data-gradient of a stride-2 conv: four parity classes, each a
+ * stride-1 pass with osy = osx = 2. */
+typedef struct cg_conv_geom {
+    int32_t N, H, W;    /* stored spatial dims of the source tensor(s) */
+    int32_t C1, C2;     /* channels of source 1 / source 2 (0 = no second source) */
+    int32_t up;         /* 1: sources are read through a nearest 2x upsample */
+    int32_t Ho, Wo;     /* enumerated output grid */
+    int32_t HoF, WoF;   /* output tensor spatial dims */
+    int32_t osy, osx, ooy, oox;
+    int32_t stride;
+    int32_t T;          /* number of taps (<= CG_MAX_TAPS) */
+    int32_t Cout;
+    int32_t act;        /* CG_ACT_* applied in the epilogue (forward only) */
+    int8_t dy[CG_MAX_TAPS];
+    int8_t dx[CG_MAX_TAPS];
+} cg_conv_geom;
+
+const char* cg_last_error(void);
+int cg_version(void);
+
+/* ---- convolution (nn.Conv2d after ZeroPad2d, networks.py:513,515-516; bare 1x1 at :44,142-143,348;
+ *      nn.Linear of the MLP as a 1x1 conv on an N x 1 x 1 x C tensor, networks.py:531) ---------- */
+
+/* y = act(conv(x) + bias).  w packed [Cout][T][C1+C2]; bias may be NULL. */
+int cg_conv2d_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
+                  const float* bias, float* y, cg_stream_t stream);
+
+/* dW[Cout][T][C1+C2] (+)= sum over output positions of dz (x) gathered input; geometry as the
+ * forward pass.  `ws` holds split-K partials: cg_conv2d_wgrad_workspace() bytes.  accumulate != 0
+ * adds into dw.  dbias (optional) = column sums of dz. */
+size_t cg_conv2d_wgrad_workspace(const cg_conv_geom* g);
+int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const float* x2, const float* dz, float* dw,
+                    float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream);
+
+/* Weight re-layout for the data-gradient pass: out[ci - ci0][tc][co] = w[co][tapmap[tc]][ci],
+ * ci in [ci0, ci0+nci).  w is [Cout][T][Cin]; out is [nci][Tc][Cout]. */
+int cg_weight_transpose(const float* w, float* out, int Cout, int T, int Cin, int ci0, int nci,
+                        const int32_t* tapmap_host, int Tc, cg_stream_t stream);
+
+/* y = act(x) (standalone activation; convs and norms normally fuse it) */
+int cg_act_fwd(const float* x, float* y, size_t n, int act, cg_stream_t stream);
+/* dz = dy * act'(y), from the activation OUTPUT y (relu / lrelu / tanh), networks.py:494-503 */
+int cg_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, cg_stream_t stream);
+
+/* ---- instance norm / AdaIN (nn.InstanceNorm2d networks.py:483; F.batch_norm on the
+ *      (1, B*C, H, W) view, networks.py:640-653), fused with activation and residual add
+ *      (ResBlock `out += residual`, networks.py:457-461) ------------------------------------ */
+
+/* mean[n*C+c], rstd[n*C+c] over HW (biased variance, eps inside the sqrt). ws: N*C*splits*2 doubles */
+size_t cg_instnorm_workspace(int N, int HW, int C);
+int cg_instnorm_stats(const float* x, int N, int HW, int C, float eps, float* mean, float* rstd, void* ws,
+                      size_t ws_bytes, cg_stream_t stream);
+/* y = act((x-mean)*rstd*gamma + beta) + residual; gamma/beta NULL = plain IN, else sample n /
+ * channel c reads gamma[n*gstride + c] (gstride = C for a dense [N*C] vector; = row length when
+ * gamma/beta point into the MLP output [N][P], networks.py:303-312); residual or NULL */
+int cg_instnorm_apply(const float* x, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, int gstride, const float* residual, float* y, int N, int HW, int C,
+                      int act, cg_stream_t stream);
+/* backward: dz = dy*act'(z); dx = rstd*gamma*(dz - mean(dz) - xhat*mean(dz*xhat));
+ * dgamma = sum dz*xhat, dbeta = sum dz (written at [n*gstride + c]; NULL for plain IN). */
+int cg_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, int gstride, float* dx, float* dgamma, float* dbeta, int N, int HW, int C,
+                    int act, void* ws, size_t ws_bytes, cg_stream_t stream);
+
+/* ---- LayerNorm (networks.py:659-686): per-sample mean / unbiased std over C*H*W, x/(std+eps),
+ *      per-channel gamma/beta --------------------------------------------------------------- */
+size_t cg_layernorm_workspace(int N, int HW, int C);
+int cg_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                     float* std, int N, int HW, int C, float eps, void* ws, size_t ws_bytes, cg_stream_t stream);
+int cg_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* std,
+                     float* dx, float* dgamma, float* dbeta, int N, int HW, int C, float eps, void* ws,
+                     size_t ws_bytes, cg_stream_t stream);
+
+/* ---- resampling --------------------------------------------------------------------------- */
+/* nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False), networks.py:32,129 */
+int cg_avgpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, cg_stream_t stream);
+int cg_avgpool3s2_bwd(const float* dy, float* dx, int N, int H, int W, int C, cg_stream_t stream);
+/* nn.Upsample(scale_factor=2) nearest, networks.py:385 (forward is normally fused into the conv gather) */
+int cg_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, cg_stream_t stream);
+int cg_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, cg_stream_t stream);
+/* nn.AdaptiveAvgPool2d(1), networks.py:347 (style encoder; forward only on the hot path) */
+int cg_global_avgpool_fwd(const float* x, float* y, int N, int HW, int C, cg_stream_t stream);
+
+/* ---- mask / blend head, Decoder_V2_atten.forward networks.py:398-407 ------------------------
+ * new_x [N,HW,od*k+k] (already tanh'ed by the last conv), im_in [N,HW,od].
+ * mask_j = (tanh(10*new_x[od*k+j])+1)/2;  im <- (1-mask_j)*im + mask_j*new_x[od*j : od*(j+1)] */
+int cg_mask_blend_fwd(const float* new_x, const float* im_in, float* im_out, float* mask, size_t npix, int od,
+                      int k, cg_stream_t stream);
+/* d_im_out [npix,od], d_mask [npix,k] (may be NULL) -> d_new_x [npix, od*k+k] */
+int cg_mask_blend_bwd(const float* new_x, const float* im_in, const float* d_im_out, const float* d_mask,
+                      float* d_new_x, size_t npix, int od, int k, cg_stream_t stream);
+
+/* ---- losses ------------------------------------------------------------------------------- */
+/* LSGAN (networks.py:64,90,166,194) over a batch of patch maps out[nb][hw]: sample s has target
+ * tgt[s] and weight wt[s]:  loss (+)= sum_s wt[s] * sum_hw (o - tgt[s])^2 / (group * hw)
+ * (`group` = samples per torch.mean, i.e. the reference batch size).  tgt / wt are device arrays. */
+int cg_lsgan_fwd(const float* out, const float* tgt, const float* wt, int nb, int hw, int group, float* loss,
+                 int accumulate, cg_stream_t stream);
+/* d_out = gscale[0] * wt[s] * 2*(o - tgt[s]) / (group*hw);  gscale is a device scalar */
+int cg_lsgan_bwd(const float* out, const float* tgt, const float* wt, const float* gscale, int nb, int hw,
+                 int group, float* d_out, cg_stream_t stream);
+
+/* Focus-loss criteria (trainer_council.py:230-250) on mask [npix_total = N*H*W][k]:
+ * sums[0] = sum 1/(|m-center|+eps), sums[1] = sum m, sums[2] = sum|dh| + sum|dw| (TV) */
+int cg_focus_sums(const float* mask, int N, int H, int W, int k, float center, float eps, float* sums,
+                  cg_stream_t stream);
+/* out[0] = w_zo*zero_one + w_total*mask_small + w_tv*tv, out[1..3] = the three unweighted criteria */
+int cg_focus_total(const float* sums, size_t numel, float w_zo, float w_total, float w_tv, int use_abs,
+                   int use_square, float* out, cg_stream_t stream);
+/* d_mask = gscale[0] * ( w_zo * d(zero_one) + w_total * d(mask_small) + w_tv * d(TV) ) / numel
+ * use_abs / use_square select mask_small's form (trainer_council.py:233-246); sums from cg_focus_sums */
+int cg_focus_bwd(const float* mask, const float* sums, const float* gscale, int N, int H, int W, int k,
+                 float center, float eps, float w_zo, float w_total, float w_tv, int use_abs, int use_square,
+                 float* d_mask, cg_stream_t stream);
+/* mean |a - b| (recon_criterion trainer_council.py:207-208 / council_basic_criterion :227-228) */
+int cg_l1_mean_fwd(const float* a, const float* b, size_t n, float* loss, cg_stream_t stream);
+int cg_l1_mean_bwd(const float* a, const float* b, const float* gscale, size_t n, float* da, cg_stream_t stream);
+
+/* ---- optimizer: torch.optim.Adam with L2 weight decay (trainer_council.py:170-179) ----------- */
+int cg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, cg_stream_t stream);
+
+/* ---- opt-in per-kernel timing (bench.py's roofline leg; off by default, no cost when off) -------
+ * While enabled, every MFMA conv launch (forward/dgrad kernel and wgrad kernel) is bracketed by
+ * HIP events recorded on the launch stream.  cg_prof_collect() synchronises them and returns, per
+ * kernel slot (slot = kernel family * 16 + tile shape * 2 + fast-path flag; see cg_prof_slot_name),
+ * launch count, total milliseconds and total algorithmic FLOPs (2*M*N*K of each launch). */
+#define CG_PROF_SLOTS 32
+int cg_prof_enable(int on);
+int cg_prof_collect(int64_t* counts, double* ms, double* flops);
+const char* cg_prof_slot_name(int slot);
+
+/* ---- small utilities ------------------------------------------------------------------------ */
+int cg_fill(float* p, size_t n, float value, cg_stream_t stream);
+int cg_add(const float* a, const float* b, float* out, size_t n, cg_stream_t stream);     /* out = a + b */
+int cg_axpby(float alpha, const float* a, float beta, float* b, size_t n, cg_stream_t stream); /* b = alpha*a + beta*b */
+/* gather rows of a stacked tensor: out[i] = src[idx[i]] (colleague pick after the all-gather) */
+int cg_gather_rows(const float* src, const int32_t* idx_dev, float* out, int nidx, size_t row_elems,
+                   cg_stream_t stream);
+/* scalar helper for the on-device loss matching (trainer_council.py:518-524,576-586):
+ * ring[pos % n] = value[0]; out[0] = mean(ring_a)/mean(ring_b) */
+int cg_loss_match(float* ring_gan, float* ring_council, int n, int pos, const float* council_loss,
+                  float* w_out, cg_stream_t stream);
+int cg_ring_push(float* ring, int n, int pos, const float* value, cg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

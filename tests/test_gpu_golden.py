@@ -1,0 +1,245 @@
+"""GPU parity of the HIP networks and of whole training iterations against (a) the golden fixtures
+recorded from the REAL reference (tests/golden/*.npz) and (b) the oracle at full network widths.
+
+Tolerances: activations / images / masks / losses / discriminator gradients
+<= 1e-3 max-abs over max-abs (measured: ~1e-6); generator gradients are judged against an fp64
+oracle because the reference's own fp32-vs-fp64 gap is 2-4e-3: err(ours, fp64) <= 2 * err(ref32, fp64)
+(with a 2e-4 floor for nets where the reference gap happens to be tiny)."""
+import copy
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Golden, case_names, rel_err, summary
+from oracle import council_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ACT_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def cga():
+    import council_gan_amd
+    council_gan_amd.hip.load()
+    return council_gan_amd
+
+
+_orig_randn, _orig_choice = torch.randn, random.choice
+
+
+@pytest.fixture(autouse=True)
+def _restore_rng_functions():
+    yield
+    torch.randn, random.choice = _orig_randn, _orig_choice
+
+
+def patch_randn(queue):
+    def randn(*shape, **k):
+        return torch.from_numpy(np.array(queue.pop(0)))
+    torch.randn = randn
+
+
+def patch_choice(queue):
+    def choice(seq):
+        c = int(queue.pop(0))
+        assert c in seq
+        return c
+    random.choice = choice
+
+
+def build_trainer(cga, cfg, state):
+    """Council_Trainer with the fixture's weights loaded through load_state_dict (checkpoint path)."""
+    tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+    for d in state:
+        for net, attr in (('gen', 'gen_%s_s'), ('dis', 'dis_%s_s'), ('dis_council', 'dis_council_%s_s')):
+            if net not in state[d]:
+                continue
+            for i, sd in enumerate(state[d][net]):
+                getattr(tr, attr % d)[i].load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+    tr.cuda('cuda:0')
+    return tr
+
+
+def np_(t):
+    return t.detach().float().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_probe_forward_vs_reference(cga, name):
+    g = Golden(name)
+    tr = build_trainer(cga, g.cfg, g.init_state())
+    s = torch.from_numpy(g["probe/style"]).cuda()
+    x = {"a2b": torch.from_numpy(g["x_a"]).cuda(), "b2a": torch.from_numpy(g["x_b"]).cuda()}
+    errs = {}
+    with torch.no_grad():
+        for d in g.dirs:
+            gen = getattr(tr, 'gen_%s_s' % d)[0]
+            xi = tr._img(x[d])
+            c, s_fake = gen.encode(xi)
+            img, mask = gen.decode(c, s, xi, return_mask=True)
+            errs[d + '/content'] = rel_err(np_(c), g["probe/%s/content" % d])
+            errs[d + '/style'] = rel_err(np_(s_fake), g["probe/%s/style_fake" % d])
+            errs[d + '/image'] = rel_err(np_(img), g["probe/%s/image" % d])
+            errs[d + '/mask'] = rel_err(np_(mask), g["probe/%s/mask" % d])
+            for sc, o in enumerate(getattr(tr, 'dis_%s_s' % d)[0].forward(img)):
+                errs[d + '/dis%d' % sc] = rel_err(np_(o), g["probe/%s/dis_out%d" % (d, sc)])
+            if "dis_council" in g.nets:
+                for sc, o in enumerate(getattr(tr, 'dis_council_%s_s' % d)[0].forward(img, xi)):
+                    errs[d + '/disc%d' % sc] = rel_err(np_(o), g["probe/%s/disc_out%d" % (d, sc)])
+    assert max(errs.values()) < ACT_TOL, errs
+
+
+def grads_of(net):
+    out = {}
+    for k, p in net.named_parameters():
+        gbuf = getattr(p, '_cg_grad', None)
+        if gbuf is not None and gbuf._cg_touched:
+            out[k] = np_(gbuf)
+    return out
+
+
+def weights_of(net):
+    return {k: np_(v) for k, v in net.state_dict().items() if 'running_' not in k}
+
+
+def l2rel(a, b):
+    num = np.sqrt(sum(float(((a[k].astype(np.float64) - b[k].astype(np.float64)) ** 2).sum()) for k in b))
+    den = np.sqrt(sum(float((b[k].astype(np.float64) ** 2).sum()) for k in b))
+    return num / max(den, 1e-30)
+
+
+def run_iteration(g, tr, cfg, it, pre, x_a, x_b, snap):
+    patch_randn(list(g[pre + "dis/randn"]))
+    tr.dis_update(x_a, x_b, cfg)
+    snap("dis")
+    if "dis_council" in g.nets and bool(g[pre + "disc/ran"]):
+        patch_randn(list(g[pre + "disc/randn"]))
+        patch_choice(list(g[pre + "disc/choice"]))
+        tr.dis_council_update(x_a, x_b, cfg)
+        snap("disc")
+    elif "dis_council" in g.nets:
+        tr.dis_council_update(x_a, x_b, cfg)      # must early-out exactly like the reference
+    patch_randn(list(g[pre + "gen/randn"]))
+    tr.gen_update(x_a, x_b, cfg, cfg["iteration"])
+    snap("gen")
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_two_iterations_vs_reference(cga, name):
+    g = Golden(name)
+    cfg = copy.deepcopy(g.cfg)
+    tr = build_trainer(cga, cfg, g.init_state())
+    # fp64 oracle twin for the generator-gradient noise floor
+    otr64 = O.OracleTrainer(copy.deepcopy(cfg), g.init_state(), dtype=torch.float64)
+    x_a, x_b = torch.from_numpy(g["x_a"]), torch.from_numpy(g["x_b"])
+    base = cfg["iteration"]
+    kinds = {"dis": ("dis", "dis_%s_s"), "disc": ("dis_council", "dis_council_%s_s"), "gen": ("gen", "gen_%s_s")}
+    report = {}
+    for it in range(2):
+        cfg["iteration"] = base + it
+        pre = "it%d/" % it
+        got = {}
+
+        def snap(kind):
+            net, attr = kinds[kind]
+            for d in g.dirs:
+                for i in range(g.C):
+                    m = getattr(tr, attr % d)[i]
+                    got[(kind, d, i)] = (grads_of(m), weights_of(m))
+        run_iteration(g, tr, cfg, it, pre, x_a, x_b, snap)
+
+        # fp64 oracle, same host-RNG replay
+        ocfg = copy.deepcopy(cfg)
+        patch_randn(list(g[pre + "dis/randn"])); otr64.dis_update(x_a, x_b, ocfg)
+        if "dis_council" in g.nets and bool(g[pre + "disc/ran"]):
+            patch_randn(list(g[pre + "disc/randn"])); patch_choice(list(g[pre + "disc/choice"]))
+            otr64.dis_council_update(x_a, x_b, ocfg)
+        patch_randn(list(g[pre + "gen/randn"])); otr64.gen_update(x_a, x_b, ocfg, ocfg["iteration"])
+        torch.randn, random.choice = _orig_randn, _orig_choice
+
+        # ---- losses -------------------------------------------------------------------------
+        def lossvec(v):
+            return np.array([float(t) for t in v])
+        np.testing.assert_allclose(lossvec(tr.loss_dis_total_s), g[pre + "dis/loss_total"], rtol=ACT_TOL)
+        if (pre + "disc/loss_total") in g:
+            np.testing.assert_allclose(lossvec(tr.loss_dis_council_total_s), g[pre + "disc/loss_total"], rtol=ACT_TOL)
+        np.testing.assert_allclose(lossvec(tr.loss_gen_total_s), g[pre + "gen/loss_total"], rtol=ACT_TOL)
+        for d in g.dirs:
+            ab = 'ab' if d == 'a2b' else 'ba'
+            np.testing.assert_allclose(lossvec(getattr(tr, 'loss_gen_adv_%s_s' % d)), g[pre + "gen/loss_adv_%s" % d],
+                                       rtol=ACT_TOL)
+            np.testing.assert_allclose(lossvec(getattr(tr, 'council_loss_%s_s' % ab)),
+                                       g[pre + "gen/council_loss_%s" % d], rtol=ACT_TOL, atol=1e-7)
+            for nm, attr in (("mask_zero_one", "loss_gen_mask_zero_one_%s_s"), ("mask_total", "loss_gen_mask_total_%s_s"),
+                             ("mask_tv", "loss_gen_mask_TV_%s_s")):
+                ref = g[pre + "gen/%s_%s" % (nm, d)]
+                if len(ref):
+                    np.testing.assert_allclose(lossvec(getattr(tr, attr % ab)), ref, rtol=ACT_TOL, atol=1e-7)
+
+        # ---- gradients and post-step weights --------------------------------------------------
+        for (kind, d, i), (gs, ws) in got.items():
+            net = kinds[kind][0]
+            ref_sum = g[pre + "%s/gradsum/%s/%d" % (kind, d, i)]
+            assert len(gs) == ref_sum.shape[0], "set of tensors that received a gradient differs (%s %s %d)" % (kind, d, i)
+            scale = ref_sum[:, 1].max()
+            mine = summary(gs)
+            if kind != "gen":
+                # discriminators: clean fp32 gradients
+                bad = np.abs(mine[:, 1] - ref_sum[:, 1]) > ACT_TOL * ref_sum[:, 1] + 1e-5 * scale
+                assert not bad.any(), (kind, d, i, mine[bad], ref_sum[bad])
+            ref_full = g.sub(pre + "%s/grad/%s/%d/" % (kind, d, i))
+            if ref_full:
+                g64 = {k: t.grad.numpy() for k, t in otr64.sd[d][net][i].items() if t.requires_grad and t.grad is not None}
+                e_ref = l2rel(ref_full, g64)
+                e_ours = l2rel({k: gs[k] for k in g64}, g64)
+                report[(it, kind, d, i)] = (e_ours, e_ref)
+                if kind == "gen":
+                    assert e_ours <= max(2 * e_ref, 2e-4), ("generator gradient", it, d, i, e_ours, e_ref)
+                else:
+                    assert e_ours <= ACT_TOL, ("discriminator gradient", kind, it, d, i, e_ours, e_ref)
+            # post-step weights: one Adam step moves every weight by <= lr; compare the bulk
+            ref_ws = g[pre + "%s/postsum/%s/%d" % (kind, d, i)]
+            minew = summary(ws)
+            assert np.all(np.abs(minew[:, 1] - ref_ws[:, 1]) <= 1e-4 * ref_ws[:, 1] + 3e-4), (kind, d, i)
+            ref_wfull = g.sub(pre + "%s/post/%s/%d/" % (kind, d, i))
+            for k, v in ref_wfull.items():
+                assert float(np.abs(ws[k] - v).mean()) < 2e-6, (kind, d, i, k)
+    print("\n[grad l2-rel vs fp64]", {k: ("%.2e" % v[0], "%.2e" % v[1]) for k, v in report.items()})
+
+
+def test_full_width_iteration_vs_oracle(cga):
+    """Real channel widths (gen dim 64 / dis dim 64, every FAST tile path) at 64x64, batch 2, council 2:
+    one full iteration against the fp32 oracle built from the trainer's own seeded weights."""
+    import os
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "configs", "male2female_council_folder.yaml")))
+    cfg['council']['council_size'] = 2
+    cfg['batch_size'] = 2
+    cfg['iteration'] = 60000
+    O.seed_all(1)
+    tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+    state = {'a2b': {'gen': [O.to_numpy_state(m.state_dict()) for m in tr.gen_a2b_s],
+                     'dis': [O.to_numpy_state(m.state_dict()) for m in tr.dis_a2b_s],
+                     'dis_council': [O.to_numpy_state(m.state_dict()) for m in tr.dis_council_a2b_s]}}
+    tr.cuda('cuda:0')
+    otr = O.OracleTrainer(copy.deepcopy(cfg), state)
+    x_a, x_b = O.synthetic_batch(2, 64)
+    st_r, st_t = random.getstate(), torch.get_rng_state()
+    tr.dis_update(x_a, x_b, cfg); tr.dis_council_update(x_a, x_b, cfg); tr.gen_update(x_a, x_b, cfg, 60000)
+    random.setstate(st_r); torch.set_rng_state(st_t)
+    otr.dis_update(x_a, x_b, cfg); otr.dis_council_update(x_a, x_b, cfg); otr.gen_update(x_a, x_b, cfg, 60000)
+    f = lambda v: np.array([float(t) for t in v])
+    np.testing.assert_allclose(f(tr.loss_dis_total_s), f(otr.loss_dis_total), rtol=ACT_TOL)
+    np.testing.assert_allclose(f(tr.loss_dis_council_total_s), f(otr.loss_disc_total), rtol=ACT_TOL)
+    np.testing.assert_allclose(f(tr.loss_gen_total_s), f(otr.loss_gen_total), rtol=ACT_TOL)
+    for i in range(2):
+        for kind, attr, onet in (("dis", tr.dis_a2b_s, "dis"), ("disc", tr.dis_council_a2b_s, "dis_council"),
+                                 ("gen", tr.gen_a2b_s, "gen")):
+            gs = grads_of(attr[i])
+            ref = {k: t.grad.numpy() for k, t in otr.sd['a2b'][onet][i].items() if t.requires_grad and t.grad is not None}
+            assert set(gs) == set(ref), (kind, set(gs) ^ set(ref))
+            e = l2rel(gs, ref)
+            assert e < (1e-2 if kind == "gen" else ACT_TOL), (kind, i, e)

@@ -1,0 +1,352 @@
+"""GPU parity of every HIP operator against a plain PyTorch CPU reference of the same op (fp64
+autograd), forward and backward, on the closed shape set of SURVEY.md 2.1 plus ragged / odd /
+tiny-channel cases.  Tolerance: max-abs error / max-abs reference <= 2e-5 (fp32 round-off of an
+fmaf chain; the 1e-3 budget of the north star is for whole-network outputs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def dev(t):
+    return t.float().cuda()
+
+
+def cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.fixture(scope="module")
+def cga():
+    import council_gan_amd
+    council_gan_amd.hip.load()
+    return council_gan_amd
+
+
+def ref_act(y, act):
+    return {"none": lambda v: v, "relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.2), "tanh": torch.tanh}[act](y)
+
+
+CONV_CASES = [
+    # name, N, H, W, C1, C2, Cout, K, stride, pad, up, act
+    ("3x3_fast_64to128", 2, 16, 16, 64, 0, 128, 3, 1, 1, 0, "relu"),
+    ("3x3_fast_256to256_tile128", 2, 64, 64, 256, 0, 256, 3, 1, 1, 0, "none"),
+    ("4x4s2_fast_64to128", 2, 32, 32, 64, 0, 128, 4, 2, 1, 0, "lrelu"),
+    ("4x4s2_fast_128to256_big", 4, 64, 64, 128, 0, 256, 4, 2, 1, 0, "none"),
+    ("7x7_cin3", 2, 32, 32, 3, 0, 64, 7, 1, 3, 0, "relu"),
+    ("1x1_64to12_tanh", 2, 16, 16, 64, 0, 12, 1, 1, 0, 0, "tanh"),
+    ("1x1_64to64_relu", 2, 64, 64, 64, 0, 64, 1, 1, 0, 0, "relu"),
+    ("1x1_512to1", 2, 8, 8, 512, 0, 1, 1, 1, 0, 0, "none"),
+    ("1x1_512to512", 3, 8, 8, 512, 0, 512, 1, 1, 0, 0, "none"),
+    ("concat_3p3to64", 2, 16, 16, 3, 3, 64, 3, 1, 1, 0, "lrelu"),
+    ("up_3x3_128to64", 2, 8, 8, 128, 0, 64, 3, 1, 1, 1, "none"),
+    ("odd_3x3_8to16", 2, 9, 7, 8, 0, 16, 3, 1, 1, 0, "relu"),
+    ("odd_4x4s2_8to16", 3, 9, 7, 8, 0, 16, 4, 2, 1, 0, "lrelu"),
+    ("odd_up_3x3_16to8", 1, 5, 3, 16, 0, 8, 3, 1, 1, 1, "none"),
+    ("4x4s2_cin3", 2, 32, 32, 3, 0, 64, 4, 2, 1, 0, "lrelu"),
+    ("tiny_1x1_c4", 1, 1, 1, 4, 0, 4, 1, 1, 0, 0, "none"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d(cga, case):
+    _, N, H, W, C1, C2, Cout, K, stride, pad, up, act = case
+    g = torch.Generator().manual_seed(sum(map(ord, case[0])))
+    x = torch.randn(N, C1, H, W, generator=g, dtype=torch.float64)
+    x2 = torch.randn(N, C2, H, W, generator=g, dtype=torch.float64) if C2 else None
+    w = torch.randn(Cout, C1 + C2, K, K, generator=g, dtype=torch.float64) / np.sqrt((C1 + C2) * K * K)
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    x2r = x2.clone().requires_grad_(True) if C2 else None
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    inp = torch.cat((xr, x2r), 1) if C2 else xr
+    if up:
+        inp = F.interpolate(inp, scale_factor=2, mode="nearest")
+    yr = ref_act(F.conv2d(F.pad(inp, (pad,) * 4), wr, br, stride=stride), act)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+
+    xd = cl(dev(x)).requires_grad_(True)
+    x2d = cl(dev(x2)).requires_grad_(True) if C2 else None
+    wd = cl(dev(w)).requires_grad_(True)
+    bd = dev(b).requires_grad_(True)
+    yd = cga.ops.conv2d(xd, wd, bd, stride, pad, act, x2=x2d, upsample=bool(up))
+    assert tuple(yd.shape) == tuple(yr.shape)
+    errs = {"fwd": rel(yd, yr)}
+    yd.backward(cl(dev(gy)))
+    errs["dx"] = rel(xd.grad, xr.grad)
+    if C2:
+        errs["dx2"] = rel(x2d.grad, x2r.grad)
+    errs["dw"] = rel(wd.grad, wr.grad)
+    errs["db"] = rel(bd.grad, br.grad)
+    assert max(errs.values()) < TOL, errs
+
+
+def test_conv2d_accumulates_into_flat_grad(cga):
+    """wgrad writes straight into a `_cg_grad` buffer (accumulate) and returns None to autograd."""
+    g = torch.Generator().manual_seed(3)
+    x = cl(dev(torch.randn(2, 32, 8, 8, generator=g)))
+    w = cl(dev(torch.randn(64, 32, 3, 3, generator=g) * 0.1)).requires_grad_(True)
+    b = dev(torch.zeros(64)).requires_grad_(True)
+    w._cg_grad = torch.ones_like(w)
+    b._cg_grad = torch.ones_like(b)
+    y = cga.ops.conv2d(x, w, b, 1, 1, "none")
+    y.sum().backward()
+    assert w.grad is None and b.grad is None
+    wc = w.detach().cpu().double().requires_grad_(True)
+    ref_w = torch.autograd.grad(F.conv2d(x.cpu().double(), wc, None, padding=1).sum(), wc)[0]
+    assert rel(w._cg_grad - 1, ref_w) < TOL
+    assert rel(b._cg_grad - 1, torch.full((64,), 2 * 8 * 8.0)) < TOL
+    assert w._cg_grad._cg_touched and b._cg_grad._cg_touched
+
+
+def test_linear(cga):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 64, generator=g, dtype=torch.float64)
+    w = torch.randn(256, 64, generator=g, dtype=torch.float64) / 8
+    b = torch.randn(256, generator=g, dtype=torch.float64)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.relu(F.linear(xr, wr, br))
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+    xd, wd, bd = (dev(t).requires_grad_(True) for t in (x, w, b))
+    yd = cga.ops.linear(xd, wd, bd, act="relu")
+    yd.backward(dev(gy))
+    errs = dict(fwd=rel(yd, yr), dx=rel(xd.grad, xr.grad), dw=rel(wd.grad, wr.grad), db=rel(bd.grad, br.grad))
+    assert max(errs.values()) < TOL, errs
+
+
+NORM_CASES = [("c64_relu_res", 2, 64, 16, 16, "relu", True), ("c256_none_res", 2, 256, 16, 16, "none", True),
+              ("c6_odd_relu", 3, 6, 9, 7, "relu", False), ("c128_big", 2, 128, 64, 64, "relu", False),
+              ("c8_lrelu", 1, 8, 5, 5, "lrelu", False)]
+
+
+@pytest.mark.parametrize("case", NORM_CASES, ids=[c[0] for c in NORM_CASES])
+@pytest.mark.parametrize("affine", [False, True], ids=["in", "adain"])
+def test_instance_norm(cga, case, affine):
+    _, N, C, H, W, act, res = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64) * 2 + 0.7
+    r = torch.randn(N, C, H, W, generator=g, dtype=torch.float64) if res else None
+    P = 2 * C + 5
+    params = torch.randn(N, P, generator=g, dtype=torch.float64)
+    boff, goff = 3, 3 + C
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    pr = params.clone().requires_grad_(True)
+    if affine:
+        y = F.batch_norm(xr.view(1, N * C, H, W), None, None, pr[:, goff:goff + C].reshape(-1),
+                         pr[:, boff:boff + C].reshape(-1), True, 0.1, 1e-5).view(N, C, H, W)
+    else:
+        y = F.instance_norm(xr, eps=1e-5)
+    yr = ref_act(y, act)
+    if res:
+        yr = yr + rr
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+
+    xd = cl(dev(x)).requires_grad_(True)
+    rd = cl(dev(r)).requires_grad_(True) if res else None
+    pd = dev(params).requires_grad_(True)
+    if affine:
+        yd = cga.ops.adain(xd, pd, goff, boff, act=act, residual=rd)
+    else:
+        yd = cga.ops.instance_norm(xd, act=act, residual=rd)
+    yd.backward(cl(dev(gy)))
+    errs = dict(fwd=rel(yd, yr), dx=rel(xd.grad, xr.grad))
+    if res:
+        errs["dres"] = rel(rd.grad, rr.grad)
+    if affine:
+        errs["dparams"] = rel(pd.grad, pr.grad)
+    assert max(errs.values()) < 5e-5, errs
+
+
+def test_layer_norm(cga):
+    g = torch.Generator().manual_seed(9)
+    N, C, H, W = 3, 16, 9, 7
+    x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64) * 1.5 + 0.3
+    gamma = torch.rand(C, generator=g, dtype=torch.float64)
+    beta = torch.randn(C, generator=g, dtype=torch.float64)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    mean = xr.reshape(N, -1).mean(1).view(N, 1, 1, 1)
+    std = xr.reshape(N, -1).std(1).view(N, 1, 1, 1)
+    yr = (xr - mean) / (std + 1e-5) * gr.view(1, -1, 1, 1) + br.view(1, -1, 1, 1)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+    xd = cl(dev(x)).requires_grad_(True)
+    gd, bd = dev(gamma).requires_grad_(True), dev(beta).requires_grad_(True)
+    yd = cga.ops.layer_norm(xd, gd, bd)
+    yd.backward(cl(dev(gy)))
+    errs = dict(fwd=rel(yd, yr), dx=rel(xd.grad, xr.grad), dg=rel(gd.grad, gr.grad), db=rel(bd.grad, br.grad))
+    assert max(errs.values()) < 5e-5, errs
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 32, 32), (2, 6, 9, 7), (1, 3, 5, 5), (2, 3, 256, 256)])
+def test_avgpool_and_upsample(cga, shape):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(*shape, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    yr = F.avg_pool2d(xr, 3, stride=2, padding=1, count_include_pad=False)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+    xd = cl(dev(x)).requires_grad_(True)
+    yd = cga.ops.avgpool3s2(xd)
+    yd.backward(cl(dev(gy)))
+    assert rel(yd, yr) < TOL and rel(xd.grad, xr.grad) < TOL
+    xr2 = x.clone().requires_grad_(True)
+    ur = F.interpolate(xr2, scale_factor=2, mode="nearest")
+    gu = torch.randn(ur.shape, generator=g, dtype=torch.float64)
+    ur.backward(gu)
+    xd2 = cl(dev(x)).requires_grad_(True)
+    ud = cga.ops.upsample2x(xd2)
+    ud.backward(cl(dev(gu)))
+    assert rel(ud, ur) < TOL and rel(xd2.grad, xr2.grad) < TOL
+
+
+def test_global_avgpool(cga):
+    x = torch.randn(3, 40, 9, 7, dtype=torch.float64)
+    yd = cga.ops.global_avgpool(cl(dev(x)))
+    assert rel(yd, F.adaptive_avg_pool2d(x, 1)) < TOL
+
+
+@pytest.mark.parametrize("od,k", [(3, 3), (3, 1), (1, 2)])
+def test_mask_blend(cga, od, k):
+    g = torch.Generator().manual_seed(13)
+    N, H, W = 2, 17, 9
+    new_x = torch.tanh(torch.randn(N, od * k + k, H, W, generator=g, dtype=torch.float64) * 0.3)
+    im = torch.rand(N, od, H, W, generator=g, dtype=torch.float64) * 2 - 1
+    nr = new_x.clone().requires_grad_(True)
+    mask = (torch.tanh(10 * nr[:, -k:]) + 1) / 2
+    out = im
+    for j in range(k):
+        m = mask[:, j:j + 1]
+        out = (1 - m) * out + m * nr[:, od * j:od * (j + 1)]
+    g_im = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    g_m = torch.randn(mask.shape, generator=g, dtype=torch.float64)
+    (out * g_im).sum().backward(retain_graph=True)
+    grad_im_only = nr.grad.clone()
+    nr.grad = None
+    ((out * g_im).sum() + (mask * g_m).sum()).backward()
+    nd = cl(dev(new_x)).requires_grad_(True)
+    od_, md = cga.ops.mask_blend(nd, cl(dev(im)), od, k)
+    assert rel(od_, out) < TOL and rel(md, mask) < TOL
+    ((od_ * cl(dev(g_im))).sum() + (md * cl(dev(g_m))).sum()).backward()
+    assert rel(nd.grad, nr.grad) < 5e-5
+    nd2 = cl(dev(new_x)).requires_grad_(True)
+    o2, _ = cga.ops.mask_blend(nd2, cl(dev(im)), od, k)
+    (o2 * cl(dev(g_im))).sum().backward()          # mask output unused -> d_mask is None
+    assert rel(nd2.grad, grad_im_only) < 5e-5
+
+
+def test_lsgan(cga):
+    g = torch.Generator().manual_seed(15)
+    B = 2
+    outs = [torch.randn(3 * B, 1, 8, 8, generator=g, dtype=torch.float64),
+            torch.randn(3 * B, 1, 4, 4, generator=g, dtype=torch.float64)]
+    tgt = [0.0] * B + [1.0] * (2 * B)
+    wt = [3.0] * B + [1.0] * B + [2.0] * B
+    refs = [o.clone().requires_grad_(True) for o in outs]
+    loss = 0
+    for o in refs:
+        loss = loss + 3 * torch.mean(o[:B] ** 2) + torch.mean((o[B:2 * B] - 1) ** 2) + 2 * torch.mean((o[2 * B:] - 1) ** 2)
+    (loss * 0.7).backward()
+    ds = [dev(o).requires_grad_(True) for o in outs]
+    ld = cga.ops.lsgan_loss(ds, dev(torch.tensor(tgt)), dev(torch.tensor(wt)), B)
+    (ld * 0.7).backward()
+    assert rel(ld, loss) < TOL
+    for d, r in zip(ds, refs):
+        assert rel(d.grad, r.grad) < TOL
+
+
+@pytest.mark.parametrize("use_abs,use_square", [(False, True), (True, False), (True, True)])
+def test_focus_loss(cga, use_abs, use_square):
+    from oracle import council_oracle as O
+    g = torch.Generator().manual_seed(17)
+    m = torch.rand(2, 3, 19, 11, generator=g, dtype=torch.float64)
+    mr = m.clone().requires_grad_(True)
+    zo = O.mask_zero_one(mr, 0.5, 0.01)
+    small = O.mask_small(mr, use_abs, use_square)
+    tv = O.mask_tv(mr)
+    total = 0.5 * zo + 57 * small + 2.2 * tv
+    (total * 1.3).backward()
+    md = cl(dev(m)).requires_grad_(True)
+    td, parts = cga.ops.focus_loss(md, 0.5, 0.01, 0.5, 57, 2.2, use_abs, use_square)
+    (td * 1.3).backward()
+    assert rel(td, total) < TOL
+    assert rel(parts, torch.stack([zo, small, tv])) < TOL
+    assert rel(md.grad, mr.grad) < 5e-5
+
+
+def test_l1_mean(cga):
+    a = torch.randn(2, 3, 9, 7, dtype=torch.float64)
+    b = torch.randn(2, 3, 9, 7, dtype=torch.float64)
+    ar = a.clone().requires_grad_(True)
+    l = torch.mean(torch.abs(ar - b))
+    l.backward()
+    ad = cl(dev(a)).requires_grad_(True)
+    ld = cga.ops.l1_mean(ad, cl(dev(b)))
+    ld.backward()
+    assert rel(ld, l) < TOL and rel(ad.grad, ar.grad) < TOL
+
+
+def test_adam_matches_torch(cga):
+    """FlatAdam == torch.optim.Adam over 3 steps, including a parameter that never gets a gradient."""
+    g = torch.Generator().manual_seed(19)
+    shapes = [(8, 4, 3, 3), (8,), (16, 8), (5,)]
+    ps = [torch.randn(*s, generator=g) for s in shapes]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    mine = [torch.nn.Parameter(p.clone()) for p in ps]
+    o_ref = torch.optim.Adam(ref, lr=1e-2, betas=(0.5, 0.999), weight_decay=1e-4)
+    o = cga.FlatAdam(mine, lr=1e-2, betas=(0.5, 0.999), weight_decay=1e-4)
+    o.materialize("cuda")
+    for step in range(3):
+        o.zero_grad()
+        o_ref.zero_grad()
+        for k, (r, m) in enumerate(zip(ref, mine)):
+            if k == 3:
+                continue          # untouched parameter: torch skips it (grad is None)
+            gr = torch.randn(*shapes[k], generator=g)
+            r.grad = gr.clone()
+            m._cg_grad.copy_(gr)
+            m._cg_grad._cg_touched = True
+        o.step()
+        o_ref.step()
+    for r, m in zip(ref, mine):
+        assert float((r.detach() - m.detach().cpu()).abs().max()) < 1e-6
+    sd = o.state_dict()
+    assert set(sd["state"]) == {0, 1, 2} and float(sd["state"][0]["step"]) == 3.0
+    assert tuple(sd["state"][0]["exp_avg"].shape) == shapes[0]
+    ref_sd = o_ref.state_dict()
+    assert rel(sd["state"][0]["exp_avg_sq"], ref_sd["state"][0]["exp_avg_sq"]) < 1e-5
+
+
+def test_loss_match_ring(cga):
+    from ctypes import c_void_p
+    hip = cga.hip
+    lib = hip.load()
+    n = 100
+    rg, rc, w = torch.ones(n, device="cuda"), torch.ones(n, device="cuda"), torch.zeros(1, device="cuda")
+    hg, hc = np.ones(n), np.ones(n)
+    for it in range(5):
+        a, c = 1.9 + 0.01 * it, 2.5 - 0.1 * it
+        hip.check(lib.cg_ring_push(hip.ptr(rg), n, it, hip.ptr(torch.tensor([a], device="cuda")), hip.stream()), "push")
+        hip.check(lib.cg_loss_match(hip.ptr(rg), hip.ptr(rc), n, it, hip.ptr(torch.tensor([c], device="cuda")),
+                                    hip.ptr(w), hip.stream()), "match")
+        hg[it % n], hc[it % n] = np.float32(a), np.float32(c)
+        assert abs(float(w) - np.mean(hg) / np.mean(hc)) < 1e-6
+
+
+def test_no_cpu_fallback(cga):
+    """A CPU tensor must be rejected loudly, never computed by some fallback."""
+    with pytest.raises(cga.hip.HipError):
+        cga.ops.conv2d(torch.randn(1, 4, 4, 4), torch.randn(4, 4, 1, 1).cuda(), None)

@@ -1,0 +1,183 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol the header declares, the
+host logic (conv geometry, flat optimizer views, trainer construction / state_dict / RNG contract,
+schedules) is right, and the product path refuses to run without a GPU instead of falling back."""
+import copy
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import council_gan_amd as cga
+from council_gan_amd import ops
+from golden_util import Golden, case_names
+from oracle import council_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "council_gan_hip.h")).read()
+    declared = set(re.findall(r"\b(cg_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"cg_stream_t"}
+    assert len(declared) >= 35
+    lib = ctypes.CDLL(cga.hip.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    # and the ctypes binding covers the same set
+    assert declared == set(cga.hip.EXPORTS), declared ^ set(cga.hip.EXPORTS)
+    assert cga.hip.load().cg_version() >= 100
+
+
+def test_geometry_struct_matches_header():
+    assert ctypes.sizeof(cga.hip.ConvGeom) == 18 * 4 + 2 * 64
+
+
+def test_no_cpu_fallback_on_hot_path():
+    x = torch.randn(1, 4, 8, 8)
+    w = torch.randn(4, 4, 3, 3)
+    with pytest.raises(cga.hip.HipError):
+        ops.conv2d(x, w, None, 1, 1)
+    cfg = Golden("glasses_c1").cfg
+    tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            tr.dis_update(torch.randn(1, 3, 32, 32), torch.randn(1, 3, 32, 32), cfg)
+    with pytest.raises(cga.hip.HipError):
+        tr.cuda('cpu')
+
+
+def _brute_dgrad(dz, w, stride, pad, Hl, Wl):
+    """dx of y = conv(x, w, stride, pad) by definition."""
+    N, Cout, Ho, Wo = dz.shape
+    _, Cin, KH, KW = w.shape
+    dx = np.zeros((N, Cin, Hl, Wl))
+    for oh in range(Ho):
+        for ow in range(Wo):
+            for kh in range(KH):
+                for kw in range(KW):
+                    ih, iw = oh * stride + kh - pad, ow * stride + kw - pad
+                    if 0 <= ih < Hl and 0 <= iw < Wl:
+                        dx[:, :, ih, iw] += np.einsum('no,oc->nc', dz[:, :, oh, ow], w[:, :, kh, kw])
+    return dx
+
+
+@pytest.mark.parametrize("K,stride,pad,Hl,Wl", [(3, 1, 1, 5, 4), (4, 2, 1, 8, 6), (4, 2, 1, 9, 7), (7, 1, 3, 6, 6),
+                                                  (1, 1, 0, 3, 3), (3, 2, 1, 7, 8)])
+def test_dgrad_parity_classes(K, stride, pad, Hl, Wl):
+    """The tap tables handed to the kernel for the data-gradient reproduce the definition."""
+    rng = np.random.RandomState(0)
+    Ho, Wo = (Hl + 2 * pad - K) // stride + 1, (Wl + 2 * pad - K) // stride + 1
+    dz = rng.randn(2, 3, Ho, Wo)
+    w = rng.randn(3, 2, K, K)
+    want = _brute_dgrad(dz, w, stride, pad, Hl, Wl)
+    got = np.full((2, 2, Hl, Wl), np.nan)
+    for ph, pw, Hc, Wc, taps in ops.dgrad_classes(Hl, Wl, K, K, stride, pad):
+        for oy in range(Hc):
+            for ox in range(Wc):
+                acc = np.zeros((2, 2))
+                for t, dy, dx in taps:
+                    iy, ix = oy + dy, ox + dx
+                    if 0 <= iy < Ho and 0 <= ix < Wo:
+                        acc += np.einsum('no,oc->nc', dz[:, :, iy, ix], w[:, :, t // K, t % K])
+                got[:, :, oy * stride + ph, ox * stride + pw] = acc
+    assert not np.isnan(got).any(), "some input position is covered by no class"
+    np.testing.assert_allclose(got, want, atol=1e-12)
+
+
+def test_fwd_geom():
+    g = ops.fwd_geom(2, 8, 8, 3, 3, 1, 3, 3, 1, 1, 16, 2)
+    assert (g.Ho, g.Wo, g.T, g.C1, g.C2, g.up) == (16, 16, 9, 3, 3, 1)
+    assert [g.dy[t] for t in range(9)] == [-1, -1, -1, 0, 0, 0, 1, 1, 1]
+    assert [g.dx[t] for t in range(9)] == [-1, 0, 1] * 3
+    g = ops.fwd_geom(1, 9, 7, 8, 0, 0, 4, 4, 2, 1, 16, 0)
+    assert (g.Ho, g.Wo) == (4, 3)
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_trainer_init_matches_reference(name):
+    """Same seeds as train.py:55-62 -> bit-identical initial weights and state_dict keys as the reference
+    (fixtures were produced by the real reference constructor)."""
+    g = Golden(name)
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    tr = cga.Council_Trainer(copy.deepcopy(g.cfg), 'cuda:0')
+    st = g.init_state()
+    for d in g.dirs:
+        for net, attr in (('gen', 'gen_%s_s'), ('dis', 'dis_%s_s'), ('dis_council', 'dis_council_%s_s')):
+            if net not in g.nets:
+                continue
+            for i in range(g.C):
+                sd = getattr(tr, attr % d)[i].state_dict()
+                assert set(sd) == set(st[d][net][i])
+                for k, v in sd.items():
+                    assert np.array_equal(v.numpy(), st[d][net][i][k]), (d, net, i, k)
+
+
+def test_adain_offsets_follow_reference_order():
+    g = Golden("m2f_c3")
+    gen = cga.AdaINGen(3, g.cfg['gen'])
+    offs = [(m.boff, m.goff, m.num_features) for m in gen.dec.modules() if isinstance(m, cga.AdaptiveInstanceNorm2d)]
+    widths = O.OracleGen({}, g.cfg['gen']).adain_layout()
+    assert [o[2] for o in offs] == widths
+    start = 0
+    for b, gm, c in offs:
+        assert (b, gm) == (start, start + c)
+        start += 2 * c
+    assert start == gen.get_num_adain_params(gen.dec)
+
+
+def test_colleague_draws_match_reference():
+    g = Golden("m2f_c3")
+    random.seed(1)
+    n_rel = g.cfg['council']['numberOfCouncil_dis_relative_iteration']
+    flat = []
+    for i in range(g.C):
+        flat += cga.Council_Trainer.draw_colleagues(i, g.C, n_rel)
+    assert flat == list(g["it0/disc/choice"])
+
+
+def test_flat_adam_views_and_state_dict_on_host():
+    """Flat buffer bookkeeping (no kernels involved): views alias the buffer, conv weights keep OIHW
+    shape with channels_last strides, torch.optim.Adam-compatible state_dict round-trips."""
+    conv = torch.nn.Conv2d(4, 8, 3)
+    lin = torch.nn.Linear(5, 3)
+    params = list(conv.parameters()) + list(lin.parameters())
+    before = [p.detach().clone() for p in params]
+    opt = cga.FlatAdam(params, lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-4)
+    opt.materialize('cpu')
+    f = opt.flat
+    assert f["data"].numel() == sum(p.numel() for p in params)
+    for p, b in zip(params, before):
+        assert torch.equal(p.detach(), b)
+        assert p.data.untyped_storage().data_ptr() == f["data"].untyped_storage().data_ptr()
+        assert p.grad is p._cg_grad
+    assert tuple(conv.weight.shape) == (8, 4, 3, 3)
+    assert conv.weight.is_contiguous(memory_format=torch.channels_last)
+    assert conv.weight.stride() == (36, 1, 12, 4)
+    conv.weight._cg_grad._cg_touched = True
+    conv.bias._cg_grad._cg_touched = True
+    assert opt.touched_runs() == [(0, 2)]
+    sd = opt.state_dict()
+    assert sd["param_groups"][0]["params"] == [0, 1, 2, 3] and sd["param_groups"][0]["betas"] == (0.5, 0.999)
+    ref = torch.optim.Adam([torch.nn.Parameter(b.clone()) for b in before], lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-4)
+    for p in ref.param_groups[0]["params"]:
+        p.grad = torch.ones_like(p)
+    ref.step()
+    opt.load_state_dict(ref.state_dict())
+    assert opt._steps == [1, 1, 1, 1]
+    back = opt.state_dict()
+    for i in range(4):
+        assert torch.allclose(back["state"][i]["exp_avg"], ref.state_dict()["state"][i]["exp_avg"])
+
+
+def test_schedules_match_oracle():
+    g = Golden("m2f_c3")
+    for it in (0, 9999, 10000, 10001, 60000):
+        for flip in (False, True):
+            hp = copy.deepcopy(g.cfg)
+            hp['iteration'] = it
+            hp['council']['flipOnOff'] = flip
+            assert cga.Council_Trainer._flip_state(hp) == O.council_flip_state(hp)
