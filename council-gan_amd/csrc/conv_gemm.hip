@@ -81,17 +81,20 @@ __device__ __forceinline__ bool tap_pixel(const cg_conv_geom& g, const RowInfo& 
 
 // ------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
+//   BM x BN block tile, WM x WN wave tile, (BM/WM)*(BN/WN) waves, STAGES LDS buffers.
+//   STAGES = 1: load(k+1) -> compute(k) -> barrier -> store(k+1) -> barrier
+//   STAGES = 2: store(k+1) -> load(k+2) -> compute(k) -> barrier        (one barrier per K-slice)
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool FAST>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(cg_conv_geom g, const float* __restrict__ x1,
-                                                       const float* __restrict__ x2,
-                                                       const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ y,
-                                                       int M, int K, int tiles_n) {
+template <int BM, int BN, int WM, int WN, bool FAST, int STAGES>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_kernel(
+    cg_conv_geom g, const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ w,
+    const float* __restrict__ bias, float* __restrict__ y, int M, int K, int tiles_n) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves per block");
+    __shared__ __attribute__((aligned(16))) float As[STAGES][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[STAGES][BN * LDK];
     __shared__ RowInfo rows[BM];
     __shared__ int taps[CG_MAX_TAPS];
 
@@ -103,9 +106,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(cg_conv_geom g, const flo
     const int Ct = g.C1 + g.C2;
 
     if (tid < g.T) taps[tid] = load_tap(tid);
-    for (int r = tid; r < BM; r += 256) {
-        rows[r] = decode_row(g, m0 + r, M, true);
-    }
+    for (int r = tid; r < BM; r += NT) rows[r] = decode_row(g, m0 + r, M, true);
     __syncthreads();
 
     f32x16 acc[TM][TN];
@@ -117,8 +118,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(cg_conv_geom g, const flo
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // staging registers
-    constexpr int A_V4 = BM / 32, B_V4 = BN / 32;  // FAST: float4 per thread
-    constexpr int A_S = BM / 8, B_S = BN / 8;      // generic: scalars per thread
+    constexpr int RPV = NT / 8;                        // FAST: rows per pass (8 float4 per 32-float row)
+    constexpr int A_V4 = BM / RPV, B_V4 = BN / RPV;    // float4 per thread
+    constexpr int RPS = NT / 32;                       // generic: rows per pass
+    constexpr int A_S = BM / RPS, B_S = BN / RPS;      // scalars per thread
+    static_assert(BM % RPV == 0 && BN % RPV == 0, "tile rows must be a multiple of the loader rows");
     float4 av[FAST ? A_V4 : 1], bv[FAST ? B_V4 : 1];
     float as[FAST ? 1 : A_S], bs[FAST ? 1 : B_S];
 
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(cg_conv_geom g, const flo
             const int td = taps[tap];
 #pragma unroll
             for (int i = 0; i < A_V4; ++i) {
-                const RowInfo ri = rows[r0 + 32 * i];
+                const RowInfo ri = rows[r0 + RPV * i];
                 int pix;
                 bool ok = tap_pixel(g, ri, td, pix);
                 av[i] = ok ? *reinterpret_cast<const float4*>(x1 + (size_t)pix * g.C1 + c0)
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(cg_conv_geom g, const flo
             }
 #pragma unroll
             for (int i = 0; i < B_V4; ++i) {
-                const int j = n0 + r0 + 32 * i;
+                const int j = n0 + r0 + RPV * i;
                 bv[i] = j < g.Cout ? *reinterpret_cast<const float4*>(w + (size_t)j * K + k0 + kc * 4)
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -158,55 +162,50 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(cg_conv_geom g, const flo
             const int cc = second ? c - g.C1 : c;
 #pragma unroll
             for (int i = 0; i < A_S; ++i) {
-                const RowInfo ri = rows[rg + 8 * i];
+                const RowInfo ri = rows[rg + RPS * i];
                 int pix;
                 bool ok = tap_pixel(g, ri, td, pix) && kv;
                 as[i] = ok ? src[(size_t)pix * cs + cc] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < B_S; ++i) {
-                const int j = n0 + rg + 8 * i;
+                const int j = n0 + rg + RPS * i;
                 bs[i] = (kv && j < g.Cout) ? w[(size_t)j * K + k] : 0.f;
             }
         }
     };
 
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
         if constexpr (FAST) {
             const int kc = tid & 7, r0 = tid >> 3;
 #pragma unroll
             for (int i = 0; i < A_V4; ++i)
-                *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDK + kc * 4]) = av[i];
+                *reinterpret_cast<float4*>(&As[buf][(r0 + RPV * i) * LDK + kc * 4]) = av[i];
 #pragma unroll
             for (int i = 0; i < B_V4; ++i)
-                *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDK + kc * 4]) = bv[i];
+                *reinterpret_cast<float4*>(&Bs[buf][(r0 + RPV * i) * LDK + kc * 4]) = bv[i];
         } else {
             const int kk = tid & 31, rg = tid >> 5;
 #pragma unroll
-            for (int i = 0; i < A_S; ++i) As[(rg + 8 * i) * LDK + kk] = as[i];
+            for (int i = 0; i < A_S; ++i) As[buf][(rg + RPS * i) * LDK + kk] = as[i];
 #pragma unroll
-            for (int i = 0; i < B_S; ++i) Bs[(rg + 8 * i) * LDK + kk] = bs[i];
+            for (int i = 0; i < B_S; ++i) Bs[buf][(rg + RPS * i) * LDK + kk] = bs[i];
         }
     };
 
     const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight under the MFMAs below
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
             float4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const float4*>(&As[(wm0 + i * 32 + l31) * LDK + ks * 8 + lh * 4]);
+                a[i] = *reinterpret_cast<const float4*>(&As[buf][(wm0 + i * 32 + l31) * LDK + ks * 8 + lh * 4]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const float4*>(&Bs[(wn0 + j * 32 + l31) * LDK + ks * 8 + lh * 4]);
+                b[j] = *reinterpret_cast<const float4*>(&Bs[buf][(wn0 + j * 32 + l31) * LDK + ks * 8 + lh * 4]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -218,9 +217,28 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(cg_conv_geom g, const flo
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    if constexpr (STAGES == 1) {
         __syncthreads();
-        if (kt + 1 < nk) {
-            store_tile();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight under the MFMAs below
+            compute(0);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                store_tile(0);
+                __syncthreads();
+            }
+        }
+    } else {
+        if (nk > 1) load_tile(1);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) store_tile((kt + 1) & 1);  // buffer last read in iteration kt-1, released by its barrier
+            if (kt + 2 < nk) load_tile(kt + 2);
+            compute(kt & 1);
             __syncthreads();
         }
     }
@@ -250,7 +268,8 @@ template <int BM, int BN, int WM, int WN, bool FAST>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const float* __restrict__ x1,
                                                          const float* __restrict__ x2,
                                                          const float* __restrict__ dz, float* __restrict__ out,
-                                                         int M, int K, int tiles_n, int slices_per_split) {
+                                                         int M, int K, int tiles_n, int slices_per_split,
+                                                         int want_bias) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int BP = 32;  // output positions per stage
@@ -386,6 +405,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const f
 
     const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
     const int l31 = lane & 31, lh = lane >> 5;
+    // bias gradient = column sums of dz: the first k-tile of every co-tile adds up the dz tile it stages anyway
+    const bool do_bias = want_bias && (tile % tiles_n == 0) && tid < BM;
+    float bsum = 0.f;
 
     if (s_begin < s_end) {
         decode_rows(s_begin, 0);
@@ -398,6 +420,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const f
             const int nb = (s - s_begin + 1) & 1;
             const bool more = s + 1 < s_end;
             if (more) load_tile(nb);  // in flight under the MFMAs
+            if (do_bias) {
+#pragma unroll 8
+                for (int p = 0; p < BP; ++p) bsum += Ds[p * BM + tid];
+            }
 #pragma unroll 4
             for (int p = 0; p < BP / 2; ++p) {
                 float a[TM], b[TN];
@@ -420,7 +446,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const f
         }
     }
 
-    float* dst = out + (size_t)split * g.Cout * K;
+    // partial layout per split: [Cout*K weight partials | Cout bias partials]
+    float* dst = out + (size_t)split * ((size_t)g.Cout * K + g.Cout);
+    if (do_bias && co0 + tid < g.Cout) dst[(size_t)g.Cout * K + co0 + tid] = bsum;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = j0 + wn0 + j * 32 + l31;
@@ -435,37 +463,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const f
     }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n, int splits,
-                                     int accumulate) {
+// dw[i] (+)= sum_s part[s][i] for the Cout*K weight partials, dbias[c] (+)= sum_s part[s][Cout*K + c]
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dbias,
+                                     size_t nw, int nb, int splits, int accumulate) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = accumulate ? dw[i] : 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
-    dw[i] = s;
-}
-
-// column sums of dz[M][C] (bias gradient): stage 1 partials per row chunk, stage 2 ordered sum
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dz, float* __restrict__ part,
-                                                             int M, int C, int rows_per_chunk) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    const int r_begin = blockIdx.y * rows_per_chunk;
-    const int r_end = min(r_begin + rows_per_chunk, M);
-    float s = 0.f;
-    if (c < C)
-        for (int r = r_begin + rl; r < r_end; r += 4) s += dz[(size_t)r * C + c];
-    red[rl][cl] = s;
-    __syncthreads();
-    if (rl == 0 && c < C) part[(size_t)blockIdx.y * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
-}
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int chunks,
-                                    int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = accumulate ? out[c] : 0.f;
-    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * C + c];
-    out[c] = s;
+    const size_t stride = nw + (size_t)nb;
+    if (i >= nw + (dbias ? (size_t)nb : 0)) return;
+    float* dst = i < nw ? dw + i : dbias + (i - nw);
+    float s = accumulate ? *dst : 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * stride + i];
+    *dst = s;
 }
 
 struct TapMap {
@@ -509,7 +516,8 @@ int tile_id(int bm, int bn) {
     if (bm == 64 && bn == 128) return 3;
     if (bm == 64 && bn == 64) return 4;
     if (bm == 32 && bn == 128) return 5;
-    return 6;
+    if (bm == 256 && bn == 128) return 6;
+    return 7;
 }
 struct ProfScope {
     bool active = false;
@@ -546,20 +554,50 @@ int validate_geom(const cg_conv_geom* g, const char* who) {
     return CG_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES>
 int launch_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias, float* y,
                int M, int K, bool fast, hipStream_t st) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (g->Cout + BN - 1) / BN;
-    dim3 grid(tiles_m * tiles_n), block(256);
+    dim3 grid(tiles_m * tiles_n), block(NT);
     ProfScope prof(0, BM, BN, fast, 2.0 * (double)M * (double)g->Cout * (double)K, st);
     if (fast)
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, *g, x1, x2, w, bias, y, M, K,
-                           tiles_n);
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true, STAGES>), grid, block, 0, st, *g, x1, x2, w, bias, y, M,
+                           K, tiles_n);
     else
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), grid, block, 0, st, *g, x1, x2, w, bias, y, M, K,
-                           tiles_n);
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false, STAGES>), grid, block, 0, st, *g, x1, x2, w, bias, y,
+                           M, K, tiles_n);
     CG_LAUNCH_CHECK("conv_fwd_kernel");
     return CG_OK;
+}
+
+// tile configurations of the forward kernel (id -> BM, BN, WM, WN, STAGES)
+int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
+                   float* y, int M, int K, bool fast, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_fwd<128, 128, 64, 64, 1>(g, x1, x2, w, bias, y, M, K, fast, st);
+        case 1: return launch_fwd<128, 64, 64, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);
+        case 2: return launch_fwd<128, 32, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);
+        case 3: return launch_fwd<64, 64, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);
+        case 4: return launch_fwd<128, 128, 64, 64, 2>(g, x1, x2, w, bias, y, M, K, fast, st);
+        case 5: return launch_fwd<128, 64, 64, 32, 2>(g, x1, x2, w, bias, y, M, K, fast, st);
+        case 6: return launch_fwd<128, 128, 64, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
+        case 7: return launch_fwd<128, 128, 64, 32, 2>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
+        case 8: return launch_fwd<64, 128, 32, 64, 1>(g, x1, x2, w, bias, y, M, K, fast, st);
+        case 9: return launch_fwd<64, 128, 32, 64, 2>(g, x1, x2, w, bias, y, M, K, fast, st);
+        case 10: return launch_fwd<64, 64, 32, 32, 2>(g, x1, x2, w, bias, y, M, K, fast, st);
+        case 11: return launch_fwd<256, 128, 64, 64, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 8 waves
+        case 12: return launch_fwd<256, 128, 64, 64, 2>(g, x1, x2, w, bias, y, M, K, fast, st);  // 8 waves
+        case 13: return launch_fwd<128, 32, 32, 32, 2>(g, x1, x2, w, bias, y, M, K, fast, st);
+        default: return cg_set_error(CG_ERR_ARG, "conv forward: unknown tile configuration %d", cfg);
+    }
+}
+
+int pick_fwd_cfg(const cg_conv_geom* g, int M) {
+    const long blocks128 = (long)((M + 127) / 128) * ((g->Cout + 127) / 128);
+    if (g->Cout > 64) return blocks128 < 128 ? 3 : 0;
+    if (g->Cout > 32) return (M + 127) / 128 < 128 ? 3 : 1;
+    return 2;
 }
 
 struct WgradPlan {
@@ -605,25 +643,23 @@ WgradPlan plan_wgrad(const cg_conv_geom* g) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_wgrad(const cg_conv_geom* g, const WgradPlan& p, const float* x1, const float* x2, const float* dz,
-                 float* out, int M, int K, hipStream_t st) {
+                 float* out, int M, int K, int want_bias, hipStream_t st) {
     dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits), block(256);
     ProfScope prof(1, BM, BN, p.fast, 2.0 * (double)M * (double)g->Cout * (double)K, st);
     if (p.fast)
         hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, *g, x1, x2, dz, out, M, K,
-                           p.tiles_n, p.slices_per_split);
+                           p.tiles_n, p.slices_per_split, want_bias);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, false>), grid, block, 0, st, *g, x1, x2, dz, out, M, K,
-                           p.tiles_n, p.slices_per_split);
+                           p.tiles_n, p.slices_per_split, want_bias);
     CG_LAUNCH_CHECK("conv_wgrad_kernel");
     return CG_OK;
 }
 
-constexpr int COLSUM_ROWS = 512;
-
 }  // namespace
 
-extern "C" int cg_conv2d_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
-                             const float* bias, float* y, cg_stream_t stream) {
+static int conv2d_fwd_impl(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
+                           float* y, int cfg, cg_stream_t stream) {
     int rc = validate_geom(g, "cg_conv2d_fwd");
     if (rc) return rc;
     CG_CHECK_ARG(x1 && w && y, "cg_conv2d_fwd: null pointer");
@@ -632,26 +668,25 @@ extern "C" int cg_conv2d_fwd(const cg_conv_geom* g, const float* x1, const float
     const int K = g->T * Ct;
     const int M = g->N * g->Ho * g->Wo;
     const bool fast = (g->C2 == 0) && (Ct % 32 == 0);
-    hipStream_t st = cg_s(stream);
-    const long blocks128 = (long)((M + 127) / 128) * ((g->Cout + 127) / 128);
-    if (g->Cout > 64) {
-        if (blocks128 < 128) return launch_fwd<64, 64, 32, 32>(g, x1, x2, w, bias, y, M, K, fast, st);
-        return launch_fwd<128, 128, 64, 64>(g, x1, x2, w, bias, y, M, K, fast, st);
-    }
-    if (g->Cout > 32) {
-        if ((M + 127) / 128 < 128) return launch_fwd<64, 64, 32, 32>(g, x1, x2, w, bias, y, M, K, fast, st);
-        return launch_fwd<128, 64, 64, 32>(g, x1, x2, w, bias, y, M, K, fast, st);
-    }
-    return launch_fwd<128, 32, 32, 32>(g, x1, x2, w, bias, y, M, K, fast, st);
+    if (cfg < 0) cfg = pick_fwd_cfg(g, M);
+    return launch_fwd_cfg(cfg, g, x1, x2, w, bias, y, M, K, fast, cg_s(stream));
+}
+
+extern "C" int cg_conv2d_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
+                             const float* bias, float* y, cg_stream_t stream) {
+    return conv2d_fwd_impl(g, x1, x2, w, bias, y, -1, stream);
+}
+
+extern "C" int cg_conv2d_fwd_tile(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
+                                  const float* bias, float* y, int tile_cfg, cg_stream_t stream) {
+    return conv2d_fwd_impl(g, x1, x2, w, bias, y, tile_cfg, stream);
 }
 
 extern "C" size_t cg_conv2d_wgrad_workspace(const cg_conv_geom* g) {
     if (!g || g->T < 1 || g->T > CG_MAX_TAPS) return 0;
     WgradPlan p = plan_wgrad(g);
     const size_t K = (size_t)g->T * (g->C1 + g->C2);
-    const int M = g->N * g->Ho * g->Wo;
-    const size_t chunks = (M + COLSUM_ROWS - 1) / COLSUM_ROWS;
-    return ((size_t)p.splits * g->Cout * K + chunks * g->Cout) * sizeof(float);
+    return (size_t)p.splits * ((size_t)g->Cout * K + g->Cout) * sizeof(float);
 }
 
 extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const float* x2, const float* dz, float* dw,
@@ -668,9 +703,8 @@ extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const flo
     hipStream_t st = cg_s(stream);
     WgradPlan p = plan_wgrad(g);
     float* part = (float*)ws;
-    const bool direct = p.splits == 1 && !accumulate;
-    float* out = direct ? dw : part;
-#define WG(BM_, BN_, WM_, WN_) rc = launch_wgrad<BM_, BN_, WM_, WN_>(g, p, x1, x2, dz, out, M, K, st)
+    const int want_bias = dbias != nullptr;
+#define WG(BM_, BN_, WM_, WN_) rc = launch_wgrad<BM_, BN_, WM_, WN_>(g, p, x1, x2, dz, part, M, K, want_bias, st)
     if (p.bm == 128 && p.bn == 128) WG(128, 128, 64, 64);
     else if (p.bm == 128 && p.bn == 64) WG(128, 64, 64, 32);
     else if (p.bm == 128 && p.bn == 32) WG(128, 32, 32, 32);
@@ -680,22 +714,11 @@ extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const flo
     else return cg_set_error(CG_ERR_ARG, "cg_conv2d_wgrad: no tile for %dx%d", p.bm, p.bn);
 #undef WG
     if (rc) return rc;
-    if (!direct) {
-        const size_t n = (size_t)g->Cout * K;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cg_div_up(n, 256)), dim3(256), 0, st, part, dw, n, p.splits,
-                           accumulate);
-        CG_LAUNCH_CHECK("splitk_reduce_kernel");
-    }
-    if (dbias) {
-        float* cpart = part + (size_t)p.splits * g->Cout * K;
-        const int chunks = (M + COLSUM_ROWS - 1) / COLSUM_ROWS;
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cg_div_up(g->Cout, 64), chunks), dim3(256), 0, st, dz, cpart, M,
-                           g->Cout, COLSUM_ROWS);
-        CG_LAUNCH_CHECK("colsum_partial_kernel");
-        hipLaunchKernelGGL(colsum_final_kernel, dim3(cg_div_up(g->Cout, 256)), dim3(256), 0, st, cpart, dbias, g->Cout,
-                           chunks, accumulate);
-        CG_LAUNCH_CHECK("colsum_final_kernel");
-    }
+    const size_t nw = (size_t)g->Cout * K;
+    const size_t n = nw + (want_bias ? g->Cout : 0);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cg_div_up(n, 256)), dim3(256), 0, st, (const float*)part, dw, dbias, nw,
+                       g->Cout, p.splits, accumulate);
+    CG_LAUNCH_CHECK("splitk_reduce_kernel");
     return CG_OK;
 }
 

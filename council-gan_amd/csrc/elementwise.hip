@@ -221,12 +221,14 @@ __global__ void lsgan_bwd_kernel(const float* __restrict__ out, const float* __r
 }
 
 // ---- focus-loss criteria, trainer_council.py:230-250 ------------------------------------------
-__global__ __launch_bounds__(1024) void focus_sums_kernel(const float* __restrict__ mask, int N, int H, int W, int k,
-                                                          float center, float eps, float* __restrict__ sums) {
-    __shared__ double red[3][16];
-    const size_t total = (size_t)N * H * W * k;
+constexpr int FOCUS_BLOCKS = 256;
+// stage 1: FOCUS_BLOCKS partial triples (fp64); stage 2: one wave adds them in a fixed order
+__global__ __launch_bounds__(256) void focus_partial_kernel(const float* __restrict__ mask, int H, int W, int k,
+                                                            size_t total, float center, float eps,
+                                                            double* __restrict__ part) {
+    __shared__ double red[3][4];
     double a = 0.0, b = 0.0, t = 0.0;
-    for (size_t i = threadIdx.x; i < total; i += 1024) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const float m = mask[i];
         size_t p = i / k;
         const int x = (int)(p % W);
@@ -246,10 +248,17 @@ __global__ __launch_bounds__(1024) void focus_sums_kernel(const float* __restric
         red[2][threadIdx.x >> 6] = t;
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 3)
+        part[(size_t)blockIdx.x * 3 + threadIdx.x] =
+            red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+__global__ __launch_bounds__(64) void focus_final_kernel(const double* __restrict__ part, int nblocks,
+                                                         float* __restrict__ sums) {
+    for (int q = 0; q < 3; ++q) {
         double s = 0.0;
-        for (int w = 0; w < 16; ++w) s += red[threadIdx.x][w];
-        sums[threadIdx.x] = (float)s;
+        for (int b = threadIdx.x; b < nblocks; b += 64) s += part[(size_t)b * 3 + q];
+        s = wave_sum_d(s);
+        if (threadIdx.x == 0) sums[q] = (float)s;
     }
 }
 __global__ void focus_total_kernel(const float* __restrict__ sums, float numel, float w_zo, float w_total, float w_tv,
@@ -474,11 +483,19 @@ extern "C" int cg_lsgan_bwd(const float* out, const float* tgt, const float* wt,
     EW_LAUNCH(lsgan_bwd_kernel, (size_t)nb * hw, out, tgt, wt, gscale, nb, hw, group, d_out);
 }
 
+extern "C" size_t cg_focus_workspace(void) { return (size_t)FOCUS_BLOCKS * 3 * sizeof(double); }
 extern "C" int cg_focus_sums(const float* mask, int N, int H, int W, int k, float center, float eps, float* sums,
-                             cg_stream_t stream) {
+                             void* ws, size_t ws_bytes, cg_stream_t stream) {
     CG_CHECK_ARG(mask && sums && N > 0 && H > 0 && W > 0 && k > 0, "cg_focus_sums: bad args");
-    hipLaunchKernelGGL(focus_sums_kernel, dim3(1), dim3(1024), 0, cg_s(stream), mask, N, H, W, k, center, eps, sums);
-    CG_LAUNCH_CHECK("focus_sums_kernel");
+    if (!ws || ws_bytes < cg_focus_workspace()) return cg_set_error(CG_ERR_WORKSPACE, "cg_focus_sums: workspace too small");
+    const size_t total = (size_t)N * H * W * k;
+    size_t nb = (total + 255) / 256;
+    if (nb > FOCUS_BLOCKS) nb = FOCUS_BLOCKS;
+    hipLaunchKernelGGL(focus_partial_kernel, dim3((unsigned)nb), dim3(256), 0, cg_s(stream), mask, H, W, k, total, center,
+                       eps, (double*)ws);
+    CG_LAUNCH_CHECK("focus_partial_kernel");
+    hipLaunchKernelGGL(focus_final_kernel, dim3(1), dim3(64), 0, cg_s(stream), (const double*)ws, (int)nb, sums);
+    CG_LAUNCH_CHECK("focus_final_kernel");
     return CG_OK;
 }
 extern "C" int cg_focus_total(const float* sums, size_t numel, float w_zo, float w_total, float w_tv, int use_abs,

@@ -42,20 +42,26 @@ __global__ __launch_bounds__(256) void in_stats_partial(const float* __restrict_
     }
 }
 
-__global__ void in_stats_final(const double* __restrict__ ws, float* __restrict__ mean, float* __restrict__ rstd,
-                               int NC, int S, int HW, float eps) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per (n, c): lanes stride over the S split partials, fixed-order butterfly combine
+__global__ __launch_bounds__(256) void in_stats_final(const double* __restrict__ ws, float* __restrict__ mean,
+                                                      float* __restrict__ rstd, int NC, int S, int HW, float eps) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= NC) return;
+    const int lane = threadIdx.x & 63;
     double a = 0.0, b = 0.0;
-    for (int s = 0; s < S; ++s) {
+    for (int s = lane; s < S; s += 64) {
         a += ws[((size_t)i * S + s) * 2];
         b += ws[((size_t)i * S + s) * 2 + 1];
     }
-    double m = a / HW;
-    double var = b / HW - m * m;  // biased variance (batch_norm training / InstanceNorm2d)
-    if (var < 0.0) var = 0.0;
-    mean[i] = (float)m;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (lane == 0) {
+        double m = a / HW;
+        double var = b / HW - m * m;  // biased variance (batch_norm training / InstanceNorm2d)
+        if (var < 0.0) var = 0.0;
+        mean[i] = (float)m;
+        rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 // y = act((x - mean) * rstd * gamma + beta) + residual
@@ -142,21 +148,27 @@ __global__ __launch_bounds__(256) void in_bwd_partial(const float* __restrict__ 
     }
 }
 
-// s12[i*2+{0,1}] = {S1/HW, S2/HW} as floats; dgamma = S2, dbeta = S1
-__global__ void in_bwd_final(const double* __restrict__ ws, float* __restrict__ s12, float* __restrict__ dgamma,
-                             float* __restrict__ dbeta, int NC, int S, int HW, int C, int gs) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// s12[i*2+{0,1}] = {S1/HW, S2/HW} as floats; dgamma = S2, dbeta = S1.  One wavefront per (n, c).
+__global__ __launch_bounds__(256) void in_bwd_final(const double* __restrict__ ws, float* __restrict__ s12,
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int NC, int S,
+                                                    int HW, int C, int gs) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= NC) return;
+    const int lane = threadIdx.x & 63;
     double a = 0.0, b = 0.0;
-    for (int s = 0; s < S; ++s) {
+    for (int s = lane; s < S; s += 64) {
         a += ws[((size_t)i * S + s) * 2];
         b += ws[((size_t)i * S + s) * 2 + 1];
     }
-    s12[i * 2] = (float)(a / HW);
-    s12[i * 2 + 1] = (float)(b / HW);
-    const int gi = (i / C) * gs + (i % C);
-    if (dgamma) dgamma[gi] = (float)b;
-    if (dbeta) dbeta[gi] = (float)a;
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (lane == 0) {
+        s12[i * 2] = (float)(a / HW);
+        s12[i * 2 + 1] = (float)(b / HW);
+        const int gi = (i / C) * gs + (i % C);
+        if (dgamma) dgamma[gi] = (float)b;
+        if (dbeta) dbeta[gi] = (float)a;
+    }
 }
 
 // dx = rstd * gamma * (dz - S1/HW - xhat * S2/HW)
@@ -334,7 +346,7 @@ extern "C" int cg_instnorm_stats(const float* x, int N, int HW, int C, float eps
     const int S = nc_splits(HW);
     hipLaunchKernelGGL(in_stats_partial, dim3(cg_div_up(C, 64), N, S), dim3(256), 0, cg_s(stream), x, (double*)ws, HW, C, S);
     CG_LAUNCH_CHECK("in_stats_partial");
-    hipLaunchKernelGGL(in_stats_final, dim3(cg_div_up((size_t)N * C, 256)), dim3(256), 0, cg_s(stream), (const double*)ws,
+    hipLaunchKernelGGL(in_stats_final, dim3(cg_div_up((size_t)N * C, 4)), dim3(256), 0, cg_s(stream), (const double*)ws,
                        mean, rstd, N * C, S, HW, eps);
     CG_LAUNCH_CHECK("in_stats_final");
     return CG_OK;
@@ -370,7 +382,7 @@ extern "C" int cg_instnorm_bwd(const float* dy, const float* x, const float* mea
     hipLaunchKernelGGL(in_bwd_partial, dim3(cg_div_up(C, 64), N, S), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma,
                        beta, part, HW, C, S, act, gstride);
     CG_LAUNCH_CHECK("in_bwd_partial");
-    hipLaunchKernelGGL(in_bwd_final, dim3(cg_div_up((size_t)N * C, 256)), dim3(256), 0, cg_s(stream), (const double*)part,
+    hipLaunchKernelGGL(in_bwd_final, dim3(cg_div_up((size_t)N * C, 4)), dim3(256), 0, cg_s(stream), (const double*)part,
                        s12, dgamma, dbeta, N * C, S, HW, C, gstride);
     CG_LAUNCH_CHECK("in_bwd_final");
     const size_t total = (size_t)N * HW * C;

@@ -34,6 +34,7 @@ _SIGS = {
     "cg_last_error": (c_char_p, []),
     "cg_version": (c_int, []),
     "cg_conv2d_fwd": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P]),
+    "cg_conv2d_fwd_tile": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P]),
     "cg_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvGeom)]),
     "cg_conv2d_wgrad": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "cg_weight_transpose": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int32), c_int, _P]),
@@ -55,7 +56,8 @@ _SIGS = {
     "cg_mask_blend_bwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
     "cg_lsgan_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     "cg_lsgan_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
-    "cg_focus_sums": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P]),
+    "cg_focus_workspace": (c_size_t, []),
+    "cg_focus_sums": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, c_size_t, _P]),
     "cg_focus_total": (c_int, [_P, c_size_t, c_float, c_float, c_float, c_int, c_int, _P, _P]),
     "cg_focus_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
                              c_int, c_int, _P, _P]),

@@ -486,7 +486,9 @@ class _FocusLoss(torch.autograd.Function):
         N, k, H, W = mask.shape
         sums = torch.empty(3, dtype=torch.float32, device=mask.device)
         out = torch.empty(4, dtype=torch.float32, device=mask.device)
-        check(lib.cg_focus_sums(ptr(mask), N, H, W, k, center, eps, ptr(sums), stream()), "cg_focus_sums")
+        ws = workspace(lib.cg_focus_workspace())
+        check(lib.cg_focus_sums(ptr(mask), N, H, W, k, center, eps, ptr(sums), ptr(ws), ws.numel(), stream()),
+              "cg_focus_sums")
         check(lib.cg_focus_total(ptr(sums), mask.numel(), w_zo, w_total, w_tv, int(use_abs), int(use_square), ptr(out),
                                  stream()), "cg_focus_total")
         ctx.save_for_backward(mask, sums)

@@ -71,9 +71,13 @@ int cg_version(void);
 int cg_conv2d_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
                   const float* bias, float* y, cg_stream_t stream);
 
+/* Same, with the block-tile configuration forced (tuning / A-B benchmarking hook; -1 = heuristic). */
+int cg_conv2d_fwd_tile(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
+                       const float* bias, float* y, int tile_cfg, cg_stream_t stream);
+
 /* dW[Cout][T][C1+C2] (+)= sum over output positions of dz (x) gathered input; geometry as the
  * forward pass.  `ws` holds split-K partials: cg_conv2d_wgrad_workspace() bytes.  accumulate != 0
- * adds into dw.  dbias (optional) = column sums of dz. */
+ * adds into dw (and dbias).  dbias (optional) = column sums of dz, accumulated inside the same kernel. */
 size_t cg_conv2d_wgrad_workspace(const cg_conv_geom* g);
 int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const float* x2, const float* dz, float* dw,
                     float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream);
@@ -148,8 +152,9 @@ int cg_lsgan_bwd(const float* out, const float* tgt, const float* wt, const floa
 
 /* Focus-loss criteria (trainer_council.py:230-250) on mask [npix_total = N*H*W][k]:
  * sums[0] = sum 1/(|m-center|+eps), sums[1] = sum m, sums[2] = sum|dh| + sum|dw| (TV) */
-int cg_focus_sums(const float* mask, int N, int H, int W, int k, float center, float eps, float* sums,
-                  cg_stream_t stream);
+size_t cg_focus_workspace(void);
+int cg_focus_sums(const float* mask, int N, int H, int W, int k, float center, float eps, float* sums, void* ws,
+                  size_t ws_bytes, cg_stream_t stream);
 /* out[0] = w_zo*zero_one + w_total*mask_small + w_tv*tv, out[1..3] = the three unweighted criteria */
 int cg_focus_total(const float* sums, size_t numel, float w_zo, float w_total, float w_tv, int use_abs,
                    int use_square, float* out, cg_stream_t stream);

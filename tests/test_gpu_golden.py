@@ -151,18 +151,27 @@ def test_two_iterations_vs_reference(cga, name):
                     got[(kind, d, i)] = (grads_of(m), weights_of(m))
         run_iteration(g, tr, cfg, it, pre, x_a, x_b, snap)
 
-        # fp64 oracle, same host-RNG replay
+        # fp64 oracle, same host-RNG replay; gradients are snapshotted right after each update (gen_update's
+        # backward also deposits gradients in the discriminators, in the oracle as in the reference)
         ocfg = copy.deepcopy(cfg)
-        patch_randn(list(g[pre + "dis/randn"])); otr64.dis_update(x_a, x_b, ocfg)
+        g64 = {}
+
+        def snap64(kind):
+            net = kinds[kind][0]
+            for d in g.dirs:
+                for i in range(g.C):
+                    g64[(kind, d, i)] = {k: t.grad.numpy().copy() for k, t in otr64.sd[d][net][i].items()
+                                         if t.requires_grad and t.grad is not None}
+        patch_randn(list(g[pre + "dis/randn"])); otr64.dis_update(x_a, x_b, ocfg); snap64("dis")
         if "dis_council" in g.nets and bool(g[pre + "disc/ran"]):
             patch_randn(list(g[pre + "disc/randn"])); patch_choice(list(g[pre + "disc/choice"]))
-            otr64.dis_council_update(x_a, x_b, ocfg)
-        patch_randn(list(g[pre + "gen/randn"])); otr64.gen_update(x_a, x_b, ocfg, ocfg["iteration"])
+            otr64.dis_council_update(x_a, x_b, ocfg); snap64("disc")
+        patch_randn(list(g[pre + "gen/randn"])); otr64.gen_update(x_a, x_b, ocfg, ocfg["iteration"]); snap64("gen")
         torch.randn, random.choice = _orig_randn, _orig_choice
 
         # ---- losses -------------------------------------------------------------------------
         def lossvec(v):
-            return np.array([float(t) for t in v])
+            return np.array([float(t.detach()) if torch.is_tensor(t) else float(t) for t in v])
         np.testing.assert_allclose(lossvec(tr.loss_dis_total_s), g[pre + "dis/loss_total"], rtol=ACT_TOL)
         if (pre + "disc/loss_total") in g:
             np.testing.assert_allclose(lossvec(tr.loss_dis_council_total_s), g[pre + "disc/loss_total"], rtol=ACT_TOL)
@@ -192,9 +201,9 @@ def test_two_iterations_vs_reference(cga, name):
                 assert not bad.any(), (kind, d, i, mine[bad], ref_sum[bad])
             ref_full = g.sub(pre + "%s/grad/%s/%d/" % (kind, d, i))
             if ref_full:
-                g64 = {k: t.grad.numpy() for k, t in otr64.sd[d][net][i].items() if t.requires_grad and t.grad is not None}
-                e_ref = l2rel(ref_full, g64)
-                e_ours = l2rel({k: gs[k] for k in g64}, g64)
+                r64 = g64[(kind, d, i)]
+                e_ref = l2rel(ref_full, r64)
+                e_ours = l2rel({k: gs[k] for k in r64}, r64)
                 report[(it, kind, d, i)] = (e_ours, e_ref)
                 if kind == "gen":
                     assert e_ours <= max(2 * e_ref, 2e-4), ("generator gradient", it, d, i, e_ours, e_ref)
@@ -204,9 +213,14 @@ def test_two_iterations_vs_reference(cga, name):
             ref_ws = g[pre + "%s/postsum/%s/%d" % (kind, d, i)]
             minew = summary(ws)
             assert np.all(np.abs(minew[:, 1] - ref_ws[:, 1]) <= 1e-4 * ref_ws[:, 1] + 3e-4), (kind, d, i)
+            # tensors whose gradient is round-off noise (conv biases feeding an instance norm) take
+            # Adam-normalised random steps of size ~lr in the reference too: excluded
+            gkeys = sorted(gs)
+            noisy = {k for k, r in zip(gkeys, ref_sum) if r[1] < 1e-6 * scale}
             ref_wfull = g.sub(pre + "%s/post/%s/%d/" % (kind, d, i))
             for k, v in ref_wfull.items():
-                assert float(np.abs(ws[k] - v).mean()) < 2e-6, (kind, d, i, k)
+                if k not in noisy:
+                    assert float(np.abs(ws[k] - v).mean()) < 2e-6, (kind, d, i, k)
     print("\n[grad l2-rel vs fp64]", {k: ("%.2e" % v[0], "%.2e" % v[1]) for k, v in report.items()})
 
 
@@ -230,16 +244,25 @@ def test_full_width_iteration_vs_oracle(cga):
     st_r, st_t = random.getstate(), torch.get_rng_state()
     tr.dis_update(x_a, x_b, cfg); tr.dis_council_update(x_a, x_b, cfg); tr.gen_update(x_a, x_b, cfg, 60000)
     random.setstate(st_r); torch.set_rng_state(st_t)
-    otr.dis_update(x_a, x_b, cfg); otr.dis_council_update(x_a, x_b, cfg); otr.gen_update(x_a, x_b, cfg, 60000)
-    f = lambda v: np.array([float(t) for t in v])
+    ref = {}
+
+    def snap(kind, onet):
+        for i in range(2):
+            ref[(kind, i)] = {k: t.grad.numpy().copy() for k, t in otr.sd['a2b'][onet][i].items()
+                              if t.requires_grad and t.grad is not None}
+    otr.dis_update(x_a, x_b, cfg); snap("dis", "dis")
+    otr.dis_council_update(x_a, x_b, cfg); snap("disc", "dis_council")
+    otr.gen_update(x_a, x_b, cfg, 60000); snap("gen", "gen")
+    f = lambda v: np.array([float(t.detach()) for t in v])
     np.testing.assert_allclose(f(tr.loss_dis_total_s), f(otr.loss_dis_total), rtol=ACT_TOL)
     np.testing.assert_allclose(f(tr.loss_dis_council_total_s), f(otr.loss_disc_total), rtol=ACT_TOL)
     np.testing.assert_allclose(f(tr.loss_gen_total_s), f(otr.loss_gen_total), rtol=ACT_TOL)
+    errs = {}
     for i in range(2):
-        for kind, attr, onet in (("dis", tr.dis_a2b_s, "dis"), ("disc", tr.dis_council_a2b_s, "dis_council"),
-                                 ("gen", tr.gen_a2b_s, "gen")):
+        for kind, attr in (("dis", tr.dis_a2b_s), ("disc", tr.dis_council_a2b_s), ("gen", tr.gen_a2b_s)):
             gs = grads_of(attr[i])
-            ref = {k: t.grad.numpy() for k, t in otr.sd['a2b'][onet][i].items() if t.requires_grad and t.grad is not None}
-            assert set(gs) == set(ref), (kind, set(gs) ^ set(ref))
-            e = l2rel(gs, ref)
-            assert e < (1e-2 if kind == "gen" else ACT_TOL), (kind, i, e)
+            assert set(gs) == set(ref[(kind, i)]), (kind, set(gs) ^ set(ref[(kind, i)]))
+            errs[(kind, i)] = l2rel(gs, ref[(kind, i)])
+    print("\n[full-width grad l2-rel vs fp32 oracle]", {k: "%.2e" % v for k, v in errs.items()})
+    for (kind, i), e in errs.items():
+        assert e < (1e-2 if kind == "gen" else ACT_TOL), (kind, i, e)

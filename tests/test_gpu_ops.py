@@ -327,7 +327,7 @@ def test_adam_matches_torch(cga):
     assert set(sd["state"]) == {0, 1, 2} and float(sd["state"][0]["step"]) == 3.0
     assert tuple(sd["state"][0]["exp_avg"].shape) == shapes[0]
     ref_sd = o_ref.state_dict()
-    assert rel(sd["state"][0]["exp_avg_sq"], ref_sd["state"][0]["exp_avg_sq"]) < 1e-5
+    assert rel(sd["state"][0]["exp_avg_sq"], ref_sd["state"][0]["exp_avg_sq"]) < 1e-4
 
 
 def test_loss_match_ring(cga):
