@@ -92,7 +92,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_kernel(
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
-    static_assert(NT == 256 || NT == 512, "4 or 8 waves per block");
+    static_assert(NT == 256 || NT == 512 || NT == 1024, "4, 8 or 16 waves per block");
     __shared__ __attribute__((aligned(16))) float As[STAGES][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[STAGES][BN * LDK];
     __shared__ RowInfo rows[BM];
@@ -265,7 +265,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_kernel(
 // weight-gradient kernel:  part[split][co][k] = sum_{m in split} dz[m][co] * A[m][k]
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool FAST>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const float* __restrict__ x1,
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_wgrad_kernel(cg_conv_geom g, const float* __restrict__ x1,
                                                          const float* __restrict__ x2,
                                                          const float* __restrict__ dz, float* __restrict__ out,
                                                          int M, int K, int tiles_n, int slices_per_split,
@@ -273,6 +273,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const f
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int BP = 32;  // output positions per stage
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves per block");
     __shared__ __attribute__((aligned(16))) float Ds[BP * BM];
     __shared__ __attribute__((aligned(16))) float Xs[BP * BN];
     __shared__ RowInfo rows[2][BP];
@@ -299,23 +301,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    constexpr int D_V4 = (BP * BM / 4) / 256;  // float4 per thread for the dz tile
-    constexpr int X_V4 = (BP * BN / 4) / 256;
-    constexpr int D_S = BP * BM / 256, X_S = BP * BN / 256;
+    constexpr int D_V4 = (BP * BM / 4) / NT;  // float4 per thread for the dz tile
+    constexpr int X_V4 = (BP * BN / 4) / NT;
+    constexpr int D_S = BP * BM / NT, X_S = BP * BN / NT;
+    static_assert((BP * BM / 4) % NT == 0 || BP * BM / 4 < NT, "dz tile / loader mismatch");
     const bool dvec = (g.Cout & 3) == 0;
     float4 dv[D_V4 > 0 ? D_V4 : 1];
-    float ds[D_S];
+    float ds[D_S > 0 ? D_S : 1];
     float4 xv[FAST ? (X_V4 > 0 ? X_V4 : 1) : 1];
-    float xs[FAST ? 1 : X_S];
+    float xs[FAST ? 1 : (X_S > 0 ? X_S : 1)];
 
     auto load_tile = [&](int buf) {
         // dz tile: rows = positions, cols = co (contiguous in memory)
         if (dvec && D_V4 > 0) {
             constexpr int CH = BM / 4;        // float4 chunks per row
-            constexpr int RP = 256 / CH;      // rows per pass
+            constexpr int RP = NT / CH;      // rows per pass
             const int ch = tid % CH, r0 = tid / CH;
 #pragma unroll
             for (int i = 0; i < (D_V4 > 0 ? D_V4 : 1); ++i) {
+                if (r0 + RP * i >= BP) break;
                 const RowInfo ri = rows[buf][r0 + RP * i];
                 const int co = co0 + ch * 4;
                 dv[i] = (ri.base >= 0 && co < g.Cout)
@@ -324,9 +328,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const f
             }
         } else {
             const int cc = tid % BM, r0 = tid / BM;
-            constexpr int RP = 256 / BM > 0 ? 256 / BM : 1;
+            constexpr int RP = NT / BM > 0 ? NT / BM : 1;
 #pragma unroll
-            for (int i = 0; i < D_S; ++i) {
+            for (int i = 0; i < (D_S > 0 ? D_S : 1); ++i) {
+                if (r0 + RP * i >= BP) break;
                 const RowInfo ri = rows[buf][r0 + RP * i];
                 const int co = co0 + cc;
                 ds[i] = (ri.base >= 0 && co < g.Cout) ? dz[(size_t)ri.out_off + co] : 0.f;
@@ -334,13 +339,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const f
         }
         if constexpr (FAST) {
             constexpr int CH = BN / 4;
-            constexpr int RP = 256 / CH;
+            constexpr int RP = NT / CH;
             const int ch = tid % CH, r0 = tid / CH;
             const int tap = j0 / Ct;
             const int c0 = j0 - tap * Ct + ch * 4;
             const int td = taps[tap];
 #pragma unroll
-            for (int i = 0; i < X_V4; ++i) {
+            for (int i = 0; i < (X_V4 > 0 ? X_V4 : 1); ++i) {
+                if (r0 + RP * i >= BP) break;
                 const RowInfo ri = rows[buf][r0 + RP * i];
                 int pix;
                 bool ok = tap_pixel(g, ri, td, pix);
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const f
             }
         } else {
             const int jj = tid % BN, r0 = tid / BN;
-            constexpr int RP = 256 / BN;
+            constexpr int RP = NT / BN;
             const int k = j0 + jj;
             const bool kv = k < K;
             const int tap = kv ? k / Ct : 0;
@@ -360,7 +366,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const f
             const int cs = second ? g.C2 : g.C1;
             const int cc = second ? c - g.C1 : c;
 #pragma unroll
-            for (int i = 0; i < X_S; ++i) {
+            for (int i = 0; i < (X_S > 0 ? X_S : 1); ++i) {
+                if (r0 + RP * i >= BP) break;
                 const RowInfo ri = rows[buf][r0 + RP * i];
                 int pix;
                 bool ok = tap_pixel(g, ri, td, pix) && kv;
@@ -372,28 +379,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(cg_conv_geom g, const f
     auto store_tile = [&]() {
         if (dvec && D_V4 > 0) {
             constexpr int CH = BM / 4;
-            constexpr int RP = 256 / CH;
+            constexpr int RP = NT / CH;
             const int ch = tid % CH, r0 = tid / CH;
 #pragma unroll
             for (int i = 0; i < (D_V4 > 0 ? D_V4 : 1); ++i)
-                *reinterpret_cast<float4*>(&Ds[(r0 + RP * i) * BM + ch * 4]) = dv[i];
+                if (r0 + RP * i < BP) *reinterpret_cast<float4*>(&Ds[(r0 + RP * i) * BM + ch * 4]) = dv[i];
         } else {
             const int cc = tid % BM, r0 = tid / BM;
-            constexpr int RP = 256 / BM > 0 ? 256 / BM : 1;
+            constexpr int RP = NT / BM > 0 ? NT / BM : 1;
 #pragma unroll
-            for (int i = 0; i < D_S; ++i) Ds[(r0 + RP * i) * BM + cc] = ds[i];
+            for (int i = 0; i < (D_S > 0 ? D_S : 1); ++i)
+                if (r0 + RP * i < BP) Ds[(r0 + RP * i) * BM + cc] = ds[i];
         }
         if constexpr (FAST) {
             constexpr int CH = BN / 4;
-            constexpr int RP = 256 / CH;
+            constexpr int RP = NT / CH;
             const int ch = tid % CH, r0 = tid / CH;
 #pragma unroll
-            for (int i = 0; i < X_V4; ++i) *reinterpret_cast<float4*>(&Xs[(r0 + RP * i) * BN + ch * 4]) = xv[i];
+            for (int i = 0; i < (X_V4 > 0 ? X_V4 : 1); ++i)
+                if (r0 + RP * i < BP) *reinterpret_cast<float4*>(&Xs[(r0 + RP * i) * BN + ch * 4]) = xv[i];
         } else {
             const int jj = tid % BN, r0 = tid / BN;
-            constexpr int RP = 256 / BN;
+            constexpr int RP = NT / BN;
 #pragma unroll
-            for (int i = 0; i < X_S; ++i) Xs[(r0 + RP * i) * BN + jj] = xs[i];
+            for (int i = 0; i < (X_S > 0 ? X_S : 1); ++i)
+                if (r0 + RP * i < BP) Xs[(r0 + RP * i) * BN + jj] = xs[i];
         }
     };
 
@@ -516,7 +526,7 @@ int tile_id(int bm, int bn) {
     if (bm == 64 && bn == 128) return 3;
     if (bm == 64 && bn == 64) return 4;
     if (bm == 32 && bn == 128) return 5;
-    if (bm == 256 && bn == 128) return 6;
+    if (bm == 256) return 6;
     return 7;
 }
 struct ProfScope {
@@ -589,14 +599,25 @@ int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float*
         case 11: return launch_fwd<256, 128, 64, 64, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 8 waves
         case 12: return launch_fwd<256, 128, 64, 64, 2>(g, x1, x2, w, bias, y, M, K, fast, st);  // 8 waves
         case 13: return launch_fwd<128, 32, 32, 32, 2>(g, x1, x2, w, bias, y, M, K, fast, st);
+        case 14: return launch_fwd<128, 64, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
+        case 15: return launch_fwd<256, 64, 64, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
+        case 16: return launch_fwd<64, 128, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
+        case 17: return launch_fwd<128, 128, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 16 waves
+        case 18: return launch_fwd<256, 128, 64, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 16 waves
         default: return cg_set_error(CG_ERR_ARG, "conv forward: unknown tile configuration %d", cfg);
     }
 }
 
+// Measured on MI355X (profiles/r01_conv_tiles.txt): 8-wave 128x128 blocks (two waves per SIMD hide each
+// other's barrier / LDS phases) reach 112-123 TFLOP/s once >= ~192 such tiles exist; problems with
+// fewer tiles fill the 256 CUs better with 64x64 tiles (two LDS stages when very few tiles).
 int pick_fwd_cfg(const cg_conv_geom* g, int M) {
     const long blocks128 = (long)((M + 127) / 128) * ((g->Cout + 127) / 128);
-    if (g->Cout > 64) return blocks128 < 128 ? 3 : 0;
-    if (g->Cout > 32) return (M + 127) / 128 < 128 ? 3 : 1;
+    if (g->Cout > 64) {
+        if (blocks128 >= 192) return 6;
+        return blocks128 < 96 ? 10 : 3;
+    }
+    if (g->Cout > 32) return (M + 127) / 128 < 192 ? 3 : 1;
     return 2;
 }
 
@@ -644,7 +665,7 @@ WgradPlan plan_wgrad(const cg_conv_geom* g) {
 template <int BM, int BN, int WM, int WN>
 int launch_wgrad(const cg_conv_geom* g, const WgradPlan& p, const float* x1, const float* x2, const float* dz,
                  float* out, int M, int K, int want_bias, hipStream_t st) {
-    dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits), block(256);
+    dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits), block((BM / WM) * (BN / WN) * 64);
     ProfScope prof(1, BM, BN, p.fast, 2.0 * (double)M * (double)g->Cout * (double)K, st);
     if (p.fast)
         hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, *g, x1, x2, dz, out, M, K,
@@ -705,7 +726,7 @@ extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const flo
     float* part = (float*)ws;
     const int want_bias = dbias != nullptr;
 #define WG(BM_, BN_, WM_, WN_) rc = launch_wgrad<BM_, BN_, WM_, WN_>(g, p, x1, x2, dz, part, M, K, want_bias, st)
-    if (p.bm == 128 && p.bn == 128) WG(128, 128, 64, 64);
+    if (p.bm == 128 && p.bn == 128) WG(128, 128, 64, 32);   // 8 waves
     else if (p.bm == 128 && p.bn == 64) WG(128, 64, 64, 32);
     else if (p.bm == 128 && p.bn == 32) WG(128, 32, 32, 32);
     else if (p.bm == 64 && p.bn == 128) WG(64, 128, 32, 64);

@@ -206,7 +206,9 @@ def test_two_iterations_vs_reference(cga, name):
                 e_ours = l2rel({k: gs[k] for k in r64}, r64)
                 report[(it, kind, d, i)] = (e_ours, e_ref)
                 if kind == "gen":
-                    assert e_ours <= max(2 * e_ref, 2e-4), ("generator gradient", it, d, i, e_ours, e_ref)
+                    # north star: within 1e-3 rel-fp32; where the reference's own fp32-vs-fp64 gap is
+                    # larger than that (steep mask head), twice that gap
+                    assert e_ours <= max(2 * e_ref, ACT_TOL), ("generator gradient", it, d, i, e_ours, e_ref)
                 else:
                     assert e_ours <= ACT_TOL, ("discriminator gradient", kind, it, d, i, e_ours, e_ref)
             # post-step weights: one Adam step moves every weight by <= lr; compare the bulk

@@ -12,7 +12,9 @@ from council_gan_amd import hip, ops  # noqa: E402
 
 CFG_NAMES = {0: "128x128/4w/1s", 1: "128x64/4w/1s", 2: "128x32/4w/1s", 3: "64x64/4w/1s", 4: "128x128/4w/2s",
              5: "128x64/4w/2s", 6: "128x128/8w/1s", 7: "128x128/8w/2s", 8: "64x128/4w/1s", 9: "64x128/4w/2s",
-             10: "64x64/4w/2s", 11: "256x128/8w/1s", 12: "256x128/8w/2s", 13: "128x32/4w/2s"}
+             10: "64x64/4w/2s", 11: "256x128/8w/1s", 12: "256x128/8w/2s", 13: "128x32/4w/2s", 14: "128x64/8w/1s",
+             15: "256x64/8w/1s", 16: "64x128/8w/1s", 17: "128x128/16w", 18: "256x128/16w"}
+SKIP = {4, 5, 7, 9, 11, 12, 13}      # double-buffered / 256x128-8w variants: measured, never better (profiles/r01_conv_tiles.txt)
 
 SHAPES = [
     # name, N, H, W, Cin, Cout, K, stride, pad, up
@@ -36,7 +38,7 @@ SHAPES = [
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     lib = hip.load()
-    cfgs = sorted(CFG_NAMES)
+    cfgs = [c for c in sorted(CFG_NAMES) if c not in SKIP]
     print("%-34s %8s | " % ("shape", "GFLOP") + " ".join("%13s" % CFG_NAMES[c] for c in cfgs))
     for name, N, H, W, Cin, Cout, K, stride, pad, up in SHAPES:
         g = ops.fwd_geom(N, H, W, Cin, 0, up, K, K, stride, pad, Cout, 1)
