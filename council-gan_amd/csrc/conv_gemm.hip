@@ -17,6 +17,7 @@
 // GEMM view (wgrad):  dW[j][k] = sum_m dz[m][j] * A[m][k]   (split over m, deterministic reduce)
 #include <stddef.h>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 #include "cg_common.h"
 
@@ -258,6 +259,268 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_kernel(
                 if (ri.base >= 0) y[(size_t)ri.out_off + col] = cg_apply_act(acc[i][j][r] + bj, g.act);
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / data-gradient kernel, software-pipelined ("pipe") -- the hot one.
+//
+// Same GEMM view and LDS image as conv_fwd_kernel<.., FAST>, restricted to single-source inputs whose
+// channel count is a multiple of BK (every K-slice lies inside one tap), but scheduled so that the
+// matrix pipe never drains around the block barrier:
+//   * two LDS buffers, ONE barrier per K-slice;
+//   * operand fragments are double-buffered in registers: the fragment for k-step s+1 is fetched from LDS
+//     while the MFMAs of k-step s run, and the first fragment of the NEXT slice is fetched right after the
+//     barrier while the last MFMAs of the current slice run -- so every wave arrives at the barrier with
+//     its next 4*TM*TN MFMAs ready to issue (operands already in VGPRs), and leaves it issuing them;
+//   * the staging work of a slice (ds_write of the prefetched global data, address arithmetic and
+//     buffer_loads of the slice after next) sits at a DIFFERENT point of the k-step sequence for the two
+//     waves that share a SIMD (waves w and w + NW/2), so one of them always feeds the matrix pipe;
+//   * the gather is branch-free: buffer_load with a hardware range check (padded taps and rows beyond
+//     M / Cout use an out-of-range offset and read as zero).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    // keep `auto`: converting the builtin's vector type to an ext_vector splats lane 0 (a dword load)
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    static_assert(sizeof(v) == sizeof(float4), "buffer_load_dwordx4");
+    return __builtin_bit_cast(float4, v);
+}
+
+constexpr unsigned CG_OOB = 0x80000000u;
+
+// timing probe of the pipelined kernel (tile configuration 31 only): per block {shader clock, 100 MHz wall clock} at
+// entry / loop start / loop end / exit, and the hardware id -- read back with cg_debug_fetch()
+constexpr int CG_DBG_WORDS = 16;
+__device__ long long cg_dbg[4096 * CG_DBG_WORDS];
+__device__ __forceinline__ void dbg_stamp(int tile, int slot) {
+    if (threadIdx.x == 0 && tile < 4096) {
+        cg_dbg[tile * CG_DBG_WORDS + slot * 2] = (long long)__builtin_amdgcn_s_memtime();
+        cg_dbg[tile * CG_DBG_WORDS + slot * 2 + 1] = (long long)wall_clock64();
+    }
+}  // >= num_records of any tensor validate_geom lets through here
+
+template <int BM, int BN, int WM, int WN, int PF, int ABL>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kernel(
+    cg_conv_geom g, const float* __restrict__ x1, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ y, int M, int K, int tiles_n, unsigned x_bytes, unsigned w_bytes) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int NW = (BM / WM) * (BN / WN);
+    constexpr int NT = NW * 64;
+    constexpr int RPV = NT / 8;                      // rows per loader pass (8 float4 per 32-float row)
+    constexpr int A_V4 = BM / RPV, B_V4 = BN / RPV;  // float4 per thread and slice
+    static_assert(BM % RPV == 0 && BN % RPV == 0, "tile rows must be a multiple of the loader rows");
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+    __shared__ RowInfo rows[BM];
+    __shared__ int taps[CG_MAX_TAPS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+    const int Ct = g.C1;
+
+    if constexpr (ABL == 3) {
+        dbg_stamp(tile, 0);
+        if (tid == 0 && tile < 4096) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            cg_dbg[tile * CG_DBG_WORDS + 8] = ((long long)xcc << 32) | hwid;
+            cg_dbg[tile * CG_DBG_WORDS + 9] = blockIdx.x;
+        }
+    }
+    if (tid < g.T) taps[tid] = load_tap(tid);
+    for (int r = tid; r < BM; r += NT) rows[r] = decode_row(g, m0 + r, M, true);
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x1, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)w_bytes, 0x00020000);
+
+    // loader role of this thread: float4 column kc of rows r0 + RPV*i of both operand tiles
+    const int kc = tid & 7, r0 = tid >> 3;
+    int rbase[A_V4], rly[A_V4], rlx[A_V4];
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) {
+        const RowInfo ri = rows[r0 + RPV * i];
+        rbase[i] = ri.base;
+        rly[i] = ri.ly0;
+        rlx[i] = ri.lx0;
+    }
+    unsigned woff[B_V4];
+#pragma unroll
+    for (int i = 0; i < B_V4; ++i) {
+        const int j = n0 + r0 + RPV * i;
+        woff[i] = (((unsigned)j * (unsigned)K + kc * 4) << 2) | (j < g.Cout ? 0u : CG_OOB);
+    }
+    const int Hl = g.H << g.up, Wl = g.W << g.up;
+    const int nk = K / BK;
+    // PF = prefetch distance in K-slices = number of staging register sets (the data of slice kt+1+PF is
+    // requested while slice kt is computed).  ABL: timing ablations only (1 = every load re-reads slice 0, results
+    // wrong; 2 = no stagger between the two waves of a SIMD).
+    static_assert(PF == 1 || PF == 2, "one or two staging register sets");
+    float4 av[PF][A_V4], bv[PF][B_V4];
+    int ld_kt = 0, ld_tap = 0, ld_c0 = 0;  // slice the next load_tile() fetches (clamped to the last slice)
+
+    auto load_tile = [&](auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+        const int td = __builtin_amdgcn_readfirstlane(taps[ld_tap]);
+        const int dy = (int)(short)(td & 0xffff), dx = td >> 16;
+        const unsigned cb = (unsigned)(ld_c0 + kc * 4);
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) {
+            const int ly = rly[i] + dy, lx = rlx[i] + dx;
+            const bool ok = rbase[i] >= 0 && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
+            const unsigned pix = (unsigned)(rbase[i] + (ly >> g.up) * g.W + (lx >> g.up));
+            // branch-free: an invalid tap only sets the top offset bit, the range check then returns zeros
+            av[SET][i] = buf_load4(xr, ((pix * (unsigned)Ct + cb) << 2) | (ok ? 0u : CG_OOB));
+        }
+        const unsigned kb = (unsigned)ld_kt * (BK * 4u);
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) bv[SET][i] = buf_load4(wr, woff[i] + kb);
+        if (ABL != 1 && ld_kt + 1 < nk) {
+            ++ld_kt;
+            ld_c0 += BK;
+            if (ld_c0 == Ct) {
+                ld_c0 = 0;
+                ++ld_tap;
+            }
+        }
+    };
+    auto store_tile = [&](int buf, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) *reinterpret_cast<float4*>(&As[buf][(r0 + RPV * i) * LDK + kc * 4]) = av[SET][i];
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) *reinterpret_cast<float4*>(&Bs[buf][(r0 + RPV * i) * LDK + kc * 4]) = bv[SET][i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int a_off = (wm0 + l31) * LDK + lh * 4, b_off = (wn0 + l31) * LDK + lh * 4;
+
+    auto read_frag = [&](int buf, int ks, float4(&a)[TM], float4(&b)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(&As[buf][a_off + i * 32 * LDK + ks * 8]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[buf][b_off + j * 32 * LDK + ks * 8]);
+    };
+    auto mma = [&](const float4(&a)[TM], const float4(&b)[TN]) {
+        // lane (l31, lh) feeds A[row l31][k], B[k][col l31] with the SAME k = ks*8 + lh*4 + e
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+    };
+
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    float4 a0[TM], b0[TN], a1[TM], b1[TN];
+    load_tile(I0());  // slice 0
+    store_tile(0, I0());
+    if constexpr (PF == 2) {
+        load_tile(I1());  // slice 1 -> set 1
+        load_tile(I0());  // slice 2 -> set 0
+    } else {
+        load_tile(I0());  // slice 1 (or slice 0 again when nk == 1) stays in registers
+    }
+    __syncthreads();
+    read_frag(0, 0, a0, b0);
+    if constexpr (ABL == 3) dbg_stamp(tile, 1);
+
+    // inside one k-step group: the LDS fetches of the NEXT fragment issue first, the MFMAs of the current one follow
+    auto group_order = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);  // MFMA
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // One K-slice out of LDS buffer CUR.  Staging = write slice kt+1 (register set SET) to the other buffer and
+    // request slice kt+1+PF into the same set; STAGE_AT selects where in the k-step sequence this wave does it.
+    auto slice = [&](auto cur_c, auto stage_at) {
+        constexpr int CUR = decltype(cur_c)::value;
+        constexpr int STAGE_AT = decltype(stage_at)::value;
+        using SET = std::integral_constant<int, PF == 2 ? (CUR ^ 1) : 0>;
+        if constexpr (STAGE_AT == 0) {
+            store_tile(CUR ^ 1, SET());
+            load_tile(SET());
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_frag(CUR, 1, a1, b1);
+        mma(a0, b0);
+        group_order();
+        if constexpr (STAGE_AT == 1) {
+            store_tile(CUR ^ 1, SET());
+            load_tile(SET());
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_frag(CUR, 2, a0, b0);
+        mma(a1, b1);
+        group_order();
+        read_frag(CUR, 3, a1, b1);
+        mma(a0, b0);
+        group_order();
+        __syncthreads();
+        read_frag(CUR ^ 1, 0, a0, b0);
+        mma(a1, b1);
+        group_order();
+    };
+    if (ABL != 2 && NW >= 8 && wid >= NW / 2) {
+        for (int kt = 0; kt + 1 < nk; kt += 2) {
+            slice(I0(), I1());
+            slice(I1(), I1());
+        }
+        if (nk & 1) slice(I0(), I1());
+    } else {
+        for (int kt = 0; kt + 1 < nk; kt += 2) {
+            slice(I0(), I0());
+            slice(I1(), I0());
+        }
+        if (nk & 1) slice(I0(), I0());
+    }
+    if constexpr (ABL == 3) dbg_stamp(tile, 2);
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + j * 32 + l31;
+        if (col >= g.Cout) continue;
+        const float bj = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const RowInfo ri = rows[row];
+                if (ri.base >= 0) y[(size_t)ri.out_off + col] = cg_apply_act(acc[i][j][r] + bj, g.act);
+            }
+        }
+    }
+    if constexpr (ABL == 3) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        dbg_stamp(tile, 3);
     }
 }
 
@@ -527,7 +790,7 @@ int tile_id(int bm, int bn) {
     if (bm == 64 && bn == 64) return 4;
     if (bm == 32 && bn == 128) return 5;
     if (bm == 256) return 6;
-    return 7;
+    return 7;  // 128x32 / 64x64-class leftovers
 }
 struct ProfScope {
     bool active = false;
@@ -538,8 +801,8 @@ struct ProfScope {
         active = true;
         rec.slot = family * 16 + tile_id(bm, bn) * 2 + (fast ? 1 : 0);
         rec.flops = flops;
-        snprintf(prof_names[rec.slot], sizeof(prof_names[0]), "%s<%d,%d,%s>", family ? "conv_wgrad_kernel" : "conv_fwd_kernel",
-                 bm, bn, fast ? "fast" : "generic");
+        static const char* const fam[3] = {"conv_fwd_kernel", "conv_wgrad_kernel", "conv_fwd_pipe_kernel"};
+        snprintf(prof_names[rec.slot], sizeof(prof_names[0]), "%s<%d,%d,%s>", fam[family], bm, bn, fast ? "fast" : "generic");
         hipEventCreate(&rec.e0);
         hipEventCreate(&rec.e1);
         hipEventRecord(rec.e0, st);
@@ -581,6 +844,27 @@ int launch_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const fl
     return CG_OK;
 }
 
+template <int BM, int BN, int WM, int WN, int PF = 1, int ABL = 0>
+int launch_fwd_pipe(const cg_conv_geom* g, const float* x1, const float* w, const float* bias, float* y, int M, int K,
+                    hipStream_t st) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (g->Cout + BN - 1) / BN;
+    const unsigned x_bytes = (unsigned)((size_t)g->N * g->H * g->W * g->C1 * sizeof(float));
+    const unsigned w_bytes = (unsigned)((size_t)g->Cout * K * sizeof(float));
+    dim3 grid(tiles_m * tiles_n), block(NT);
+    ProfScope prof(2, BM, BN, true, 2.0 * (double)M * (double)g->Cout * (double)K, st);
+    hipLaunchKernelGGL((conv_fwd_pipe_kernel<BM, BN, WM, WN, PF, ABL>), grid, block, 0, st, *g, x1, w, bias, y, M, K, tiles_n,
+                       x_bytes, w_bytes);
+    CG_LAUNCH_CHECK("conv_fwd_pipe_kernel");
+    return CG_OK;
+}
+
+// the pipelined kernel needs: one source, channels a multiple of BK, operands addressable with 31-bit byte offsets
+bool pipe_ok(const cg_conv_geom* g, int K) {
+    return g->C2 == 0 && g->C1 % BK == 0 && (size_t)g->N * g->H * g->W * g->C1 * sizeof(float) < (size_t)CG_OOB &&
+           (size_t)g->Cout * K * sizeof(float) < (size_t)CG_OOB;
+}
+
 // tile configurations of the forward kernel (id -> BM, BN, WM, WN, STAGES)
 int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
                    float* y, int M, int K, bool fast, hipStream_t st) {
@@ -604,6 +888,22 @@ int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float*
         case 16: return launch_fwd<64, 128, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
         case 17: return launch_fwd<128, 128, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 16 waves
         case 18: return launch_fwd<256, 128, 64, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 16 waves
+        case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31:
+            if (!pipe_ok(g, K)) return cg_set_error(CG_ERR_ARG, "conv forward: configuration %d needs the pipelined path", cfg);
+            switch (cfg) {
+                case 20: return launch_fwd_pipe<128, 128, 64, 32>(g, x1, w, bias, y, M, K, st);  // 8 waves
+                case 21: return launch_fwd_pipe<128, 128, 64, 64>(g, x1, w, bias, y, M, K, st);  // 4 waves
+                case 22: return launch_fwd_pipe<128, 64, 64, 32>(g, x1, w, bias, y, M, K, st);   // 4 waves
+                case 23: return launch_fwd_pipe<64, 64, 32, 32>(g, x1, w, bias, y, M, K, st);    // 4 waves
+                case 24: return launch_fwd_pipe<256, 128, 64, 64>(g, x1, w, bias, y, M, K, st);  // 8 waves
+                case 25: return launch_fwd_pipe<128, 64, 32, 32>(g, x1, w, bias, y, M, K, st);   // 8 waves
+                case 27: return launch_fwd_pipe<128, 128, 64, 32, 2>(g, x1, w, bias, y, M, K, st);     // prefetch 2
+                case 28: return launch_fwd_pipe<128, 128, 64, 32, 1, 1>(g, x1, w, bias, y, M, K, st);  // ablation
+                case 29: return launch_fwd_pipe<128, 128, 64, 32, 1, 2>(g, x1, w, bias, y, M, K, st);  // ablation
+                case 30: return launch_fwd_pipe<128, 128, 64, 64, 2>(g, x1, w, bias, y, M, K, st);     // 4 waves, prefetch 2
+                case 31: return launch_fwd_pipe<128, 128, 64, 32, 1, 3>(g, x1, w, bias, y, M, K, st);  // timing probe
+                default: return launch_fwd_pipe<64, 128, 32, 64>(g, x1, w, bias, y, M, K, st);   // 4 waves
+            }
         default: return cg_set_error(CG_ERR_ARG, "conv forward: unknown tile configuration %d", cfg);
     }
 }
@@ -611,13 +911,17 @@ int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float*
 // Measured on MI355X (profiles/r01_conv_tiles.txt): 8-wave 128x128 blocks (two waves per SIMD hide each
 // other's barrier / LDS phases) reach 112-123 TFLOP/s once >= ~192 such tiles exist; problems with
 // fewer tiles fill the 256 CUs better with 64x64 tiles (two LDS stages when very few tiles).
-int pick_fwd_cfg(const cg_conv_geom* g, int M) {
+int pick_fwd_cfg(const cg_conv_geom* g, int M, bool pipe) {
     const long blocks128 = (long)((M + 127) / 128) * ((g->Cout + 127) / 128);
     if (g->Cout > 64) {
-        if (blocks128 >= 192) return 6;
+        if (blocks128 >= 192) return pipe ? 20 : 6;
+        if (pipe) return 23;
         return blocks128 < 96 ? 10 : 3;
     }
-    if (g->Cout > 32) return (M + 127) / 128 < 192 ? 3 : 1;
+    if (g->Cout > 32) {
+        if ((M + 127) / 128 < 192) return pipe ? 23 : 3;
+        return pipe ? 22 : 1;
+    }
     return 2;
 }
 
@@ -689,7 +993,7 @@ static int conv2d_fwd_impl(const cg_conv_geom* g, const float* x1, const float* 
     const int K = g->T * Ct;
     const int M = g->N * g->Ho * g->Wo;
     const bool fast = (g->C2 == 0) && (Ct % 32 == 0);
-    if (cfg < 0) cfg = pick_fwd_cfg(g, M);
+    if (cfg < 0) cfg = pick_fwd_cfg(g, M, fast && pipe_ok(g, K));
     return launch_fwd_cfg(cfg, g, x1, x2, w, bias, y, M, K, fast, cg_s(stream));
 }
 
@@ -757,6 +1061,13 @@ extern "C" int cg_weight_transpose(const float* w, float* out, int Cout, int T, 
     dim3 grid(cg_div_up(nci, 32), cg_div_up(Cout, 32), Tc);
     hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, cg_s(stream), w, out, Cout, T, Cin, ci0, nci, tm, Tc);
     CG_LAUNCH_CHECK("weight_transpose_kernel");
+    return CG_OK;
+}
+
+extern "C" int cg_debug_fetch(long long* host, int nwords) {
+    CG_CHECK_ARG(host && nwords > 0 && nwords <= 4096 * CG_DBG_WORDS, "cg_debug_fetch: bad args");
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(cg_dbg), (size_t)nwords * sizeof(long long));
+    if (e != hipSuccess) return cg_set_error(CG_ERR_LAUNCH, "cg_debug_fetch: %s", hipGetErrorString(e));
     return CG_OK;
 }
 

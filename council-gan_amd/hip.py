@@ -70,6 +70,7 @@ _SIGS = {
     "cg_gather_rows": (c_int, [_P, _P, _P, c_int, c_size_t, _P]),
     "cg_loss_match": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
     "cg_ring_push": (c_int, [_P, c_int, c_int, _P, _P]),
+    "cg_debug_fetch": (c_int, [POINTER(c_int64), c_int]),
     "cg_prof_enable": (c_int, [c_int]),
     "cg_prof_collect": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     "cg_prof_slot_name": (c_char_p, [c_int]),
@@ -135,7 +136,7 @@ def workspace(nbytes):
     return buf
 
 
-PROF_SLOTS = 32
+PROF_SLOTS = 48
 
 
 def prof_enable(on):

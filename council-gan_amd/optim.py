@@ -37,6 +37,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._params = params
         self._flat = None
         self._steps = [0] * len(params)
+        self.version = 0          # bumped whenever the parameter values may have changed (step / load / move)
 
     # -- flat storage ---------------------------------------------------------------------
     def materialize(self, device):
@@ -66,6 +67,7 @@ class FlatAdam(torch.optim.Optimizer):
             offs.append(off)
             off += n
         self._flat = dict(data=data, grad=grad, m=m, v=v, offs=offs, sizes=sizes)
+        self.version += 1
 
     @property
     def flat(self):
@@ -104,6 +106,7 @@ class FlatAdam(torch.optim.Optimizer):
         grp = self.param_groups[0]
         b1, b2 = grp["betas"]
         lib = hip.load()
+        self.version += 1
         for i0, i1 in self.touched_runs():
             off = f["offs"][i0]
             n = f["offs"][i1 - 1] + f["sizes"][i1 - 1] - off
@@ -135,6 +138,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, sd):
         f = self.flat
+        self.version += 1
         for i, p in enumerate(self._params):
             st = sd["state"].get(i, sd["state"].get(str(i)))
             off = f["offs"][i]

@@ -176,6 +176,10 @@ class Council_Trainer(nn.Module):
         self._ring_pos_c = {d: [0] * self.council_size for d in self._dirs}
         self._rings = None
         self._device = None
+        # content-code cache ("re-encoding identical c_a"): the three updates of one iteration
+        # encode the SAME batch with the SAME generator weights, so the encoder runs once per iteration
+        self._img_cache = {}
+        self._enc_cache = {}
 
     # ------------------------------------------------------------------------------------
     # device placement
@@ -214,8 +218,36 @@ class Council_Trainer(nn.Module):
         if self._device is None:
             self.cuda(self.cuda_device)
 
-    def _img(self, x):
-        return x.to(self._device, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+    def _img(self, x, slot=None):
+        """Device / NHWC copy of a caller tensor.  The copy is re-used while the caller passes the very same
+        (unmodified) tensor object again -- train.py:244-250 hands one batch to all three updates."""
+        ent = self._img_cache.get(slot) if slot is not None else None
+        if ent is not None and ent[0] is x and ent[1] == x._version:
+            return ent[2]
+        y = x.to(self._device, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+        if slot is not None:
+            self._img_cache[slot] = (x, x._version, y)     # holding `x` keeps its address from being recycled
+        return y
+
+    def _weights_version(self, d, i):
+        gen = self._nets('gen', d)[i]
+        return (self.gen_opt_s[i].version, sum(p._version for p in gen.enc_content.parameters()))
+
+    def _content(self, d, i, x, need_grad):
+        """Content code of member i for batch x (the NHWC device copy from _img).  Encoded once per (batch,
+        generator weights) with the autograd tape attached; the discriminator updates use it detached, gen_update
+        back-propagates through it (and drops it, the tape being consumed)."""
+        key = (id(x), self._weights_version(d, i))
+        ent = self._enc_cache.get((d, i))
+        if ent is None or ent[0] != key or ent[1] is not x:
+            with torch.enable_grad():
+                content = self._nets('gen', d)[i].encode_content(x)
+            ent = (key, x, content)
+            self._enc_cache[(d, i)] = ent
+        if need_grad:
+            del self._enc_cache[(d, i)]
+            return ent[2]
+        return ent[2].detach()
 
     def _noise(self, n):
         # CPU RNG then upload, exactly as the reference (trainer_council.py:284-285,741,744,807-809)
@@ -238,7 +270,7 @@ class Council_Trainer(nn.Module):
     def dis_update(self, x_a=None, x_b=None, hyperparameters=None):
         hp = hyperparameters
         self._ready()
-        x = {'a2b': self._img(x_a), 'b2a': self._img(x_b)}      # source image per direction
+        x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}      # source image per direction
         tgt = {'a2b': x['b2a'], 'b2a': x['a2b']}                 # real image of the target domain
         for i in self.shard.local:
             self.dis_opt_s[i].zero_grad()
@@ -254,8 +286,9 @@ class Council_Trainer(nn.Module):
             total = None
             for d in self._dirs:
                 gen = self._nets('gen', d)[i]
+                content = self._content(d, i, x[d], need_grad=False)
                 with torch.no_grad():
-                    x_fake = gen.decode(gen.encode_content(x[d]), s[d], x[d])
+                    x_fake = gen.decode(content, s[d], x[d])
                 # :775-777 -- only the a2b term is scaled by gan_w (reference quirk, kept); the scale is
                 # folded into the per-sample loss weights
                 w = float(hp['gan_w']) if d == 'a2b' else 1.0
@@ -281,7 +314,7 @@ class Council_Trainer(nn.Module):
         if not self.do_council_loss or hp['council_w'] == 0 or hp['iteration'] < c['council_start_at_iter']:
             return
         self._ready()
-        x = {'a2b': self._img(x_a), 'b2a': self._img(x_b)}
+        x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}
         for i in self.shard.local:
             self.dis_council_opt_s[i].zero_grad()
         s, s_less = {}, {}
@@ -298,11 +331,11 @@ class Council_Trainer(nn.Module):
 
         x_full = {d: {} for d in self._dirs}
         x_cmp_local = {d: [] for d in self._dirs}
-        with torch.no_grad():
-            for i in self.shard.local:
-                for d in self._dirs:
-                    gen = self._nets('gen', d)[i]
-                    content = gen.encode_content(x[d])
+        for i in self.shard.local:
+            for d in self._dirs:
+                gen = self._nets('gen', d)[i]
+                content = self._content(d, i, x[d], need_grad=False)
+                with torch.no_grad():
                     x_full[d][i] = gen.decode(content, s[d], x[d])
                     x_cmp_local[d].append(gen.decode(content, s_less[d], x[d]) if less != 0 else x_full[d][i])
         # the ONE cross-member exchange (trainer_council.py:853-856): every member's comparison image
@@ -351,7 +384,7 @@ class Council_Trainer(nn.Module):
         self.hyperparameters = hp
         self._ready()
         lib = hip.load()
-        x = {'a2b': self._img(x_a), 'b2a': self._img(x_b)}
+        x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}
         for i in self.shard.local:
             self.gen_opt_s[i].zero_grad()
         s_a = self._noise(x_a.size(0)).to(self._device)     # both drawn, s_a first (:284-285)
@@ -398,7 +431,7 @@ class Council_Trainer(nn.Module):
                 total = None
                 for d in self._dirs:
                     gen = self._nets('gen', d)[i]
-                    x_fake = gen.decode(gen.encode_content(x[d]), s[d], x[d])
+                    x_fake = gen.decode(self._content(d, i, x[d], need_grad=True), s[d], x[d])
                     mask = gen.dec.mask_s
                     terms = []
                     if focus_on:                                                   # :390-451

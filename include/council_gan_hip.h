@@ -176,10 +176,14 @@ int cg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
  * HIP events recorded on the launch stream.  cg_prof_collect() synchronises them and returns, per
  * kernel slot (slot = kernel family * 16 + tile shape * 2 + fast-path flag; see cg_prof_slot_name),
  * launch count, total milliseconds and total algorithmic FLOPs (2*M*N*K of each launch). */
-#define CG_PROF_SLOTS 32
+#define CG_PROF_SLOTS 48
 int cg_prof_enable(int on);
 int cg_prof_collect(int64_t* counts, double* ms, double* flops);
 const char* cg_prof_slot_name(int slot);
+
+/* Timing probe (development aid): after a cg_conv2d_fwd_tile() launch with tile_cfg 31, 16 words per block --
+ * {shader clock, 100 MHz wall clock} at kernel entry / loop start / loop end / exit, hardware id, block id. */
+int cg_debug_fetch(long long* host, int nwords);
 
 /* ---- small utilities ------------------------------------------------------------------------ */
 int cg_fill(float* p, size_t n, float value, cg_stream_t stream);

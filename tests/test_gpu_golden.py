@@ -185,8 +185,18 @@ def test_two_iterations_vs_reference(cga, name):
             for nm, attr in (("mask_zero_one", "loss_gen_mask_zero_one_%s_s"), ("mask_total", "loss_gen_mask_total_%s_s"),
                              ("mask_tv", "loss_gen_mask_TV_%s_s")):
                 ref = g[pre + "gen/%s_%s" % (nm, d)]
-                if len(ref):
-                    np.testing.assert_allclose(lossvec(getattr(tr, attr % ab)), ref, rtol=ACT_TOL, atol=1e-7)
+                if not len(ref):
+                    continue
+                mine = lossvec(getattr(tr, attr % ab))
+                if nm == "mask_zero_one":
+                    # mean 1/(|m-c|+eps) amplifies a mask perturbation by up to 1/eps^2: the reference's own fp32
+                    # value is off its fp64 value by more than 1e-3 on some fixtures, so this criterion is judged
+                    # like the generator gradients -- distance to the fp64 oracle, at most twice the reference's
+                    r64 = lossvec(otr64.loss_mask_zero_one[d])
+                    tol = np.maximum(ACT_TOL * np.abs(r64), 2 * np.abs(ref - r64)) + 1e-7
+                    assert np.all(np.abs(mine - r64) <= tol), (nm, d, mine, ref, r64)
+                else:
+                    np.testing.assert_allclose(mine, ref, rtol=ACT_TOL, atol=1e-7)
 
         # ---- gradients and post-step weights --------------------------------------------------
         for (kind, d, i), (gs, ws) in got.items():
@@ -268,3 +278,38 @@ def test_full_width_iteration_vs_oracle(cga):
     print("\n[full-width grad l2-rel vs fp32 oracle]", {k: "%.2e" % v for k, v in errs.items()})
     for (kind, i), e in errs.items():
         assert e < (1e-2 if kind == "gen" else ACT_TOL), (kind, i, e)
+
+
+def test_content_cache_is_invalidated(cga):
+    """The encoder runs once per (batch, generator weights): a batch modified in place, a new batch object and a
+    generator step must each force a re-encode (trainer._content)."""
+    import os
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "configs", "male2female_council_folder.yaml")))
+    cfg['gen'].update(dim=8, mlp_dim=16, n_res=1)
+    cfg['dis'].update(dim=8)
+    cfg['council']['council_size'] = 2
+    cfg['batch_size'] = 2
+    cfg['iteration'] = 60000
+    O.seed_all(3)
+    tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+    tr.cuda('cuda:0')
+    x_a, x_b = O.synthetic_batch(2, 32)
+    x_a, x_b = x_a.cuda(), x_b.cuda()
+
+    def fresh(x):
+        with torch.no_grad():
+            return tr.gen_a2b_s[0].encode_content(tr._img(x)).clone()
+
+    tr.dis_update(x_a, x_b, cfg)
+    c0 = tr._content('a2b', 0, tr._img(x_a, 'a'), need_grad=False)
+    assert torch.equal(c0, fresh(x_a))
+    x_a.mul_(0.5)                                   # in-place edit of the same tensor object
+    tr.dis_council_update(x_a, x_b, cfg)
+    c1 = tr._content('a2b', 0, tr._img(x_a, 'a'), need_grad=False)
+    assert torch.equal(c1, fresh(x_a)) and not torch.equal(c0, c1)
+    tr.gen_update(x_a, x_b, cfg, 60000)             # generator step: weights changed, tape consumed
+    assert ('a2b', 0) not in tr._enc_cache
+    tr.dis_update(x_a, x_b, cfg)
+    c2 = tr._content('a2b', 0, tr._img(x_a, 'a'), need_grad=False)
+    assert torch.equal(c2, fresh(x_a)) and not torch.equal(c1, c2)

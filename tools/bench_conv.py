@@ -13,8 +13,11 @@ from council_gan_amd import hip, ops  # noqa: E402
 CFG_NAMES = {0: "128x128/4w/1s", 1: "128x64/4w/1s", 2: "128x32/4w/1s", 3: "64x64/4w/1s", 4: "128x128/4w/2s",
              5: "128x64/4w/2s", 6: "128x128/8w/1s", 7: "128x128/8w/2s", 8: "64x128/4w/1s", 9: "64x128/4w/2s",
              10: "64x64/4w/2s", 11: "256x128/8w/1s", 12: "256x128/8w/2s", 13: "128x32/4w/2s", 14: "128x64/8w/1s",
-             15: "256x64/8w/1s", 16: "64x128/8w/1s", 17: "128x128/16w", 18: "256x128/16w"}
-SKIP = {4, 5, 7, 9, 11, 12, 13}      # double-buffered / 256x128-8w variants: measured, never better (profiles/r01_conv_tiles.txt)
+             15: "256x64/8w/1s", 16: "64x128/8w/1s", 17: "128x128/16w", 18: "256x128/16w",
+             20: "P128x128/8w", 21: "P128x128/4w", 22: "P128x64/4w", 23: "P64x64/4w", 24: "P256x128/8w",
+             25: "P128x64/8w", 26: "P64x128/4w", 27: "P128x128/8w/pf2", 28: "abl:fixedslice", 29: "abl:nostagger",
+             30: "P128x128/4w/pf2"}
+SKIP = {1, 2, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18}      # double-buffered / 256x128-8w variants: measured, never better (profiles/r01_conv_tiles.txt)
 
 SHAPES = [
     # name, N, H, W, Cin, Cout, K, stride, pad, up
@@ -39,8 +42,13 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     lib = hip.load()
     cfgs = [c for c in sorted(CFG_NAMES) if c not in SKIP]
+    if os.environ.get("CFGS"):
+        cfgs = [int(c) for c in os.environ["CFGS"].split(",")]
+    shapes = SHAPES
+    if os.environ.get("SHAPES"):
+        shapes = [SHAPES[int(i)] for i in os.environ["SHAPES"].split(",")]
     print("%-34s %8s | " % ("shape", "GFLOP") + " ".join("%13s" % CFG_NAMES[c] for c in cfgs))
-    for name, N, H, W, Cin, Cout, K, stride, pad, up in SHAPES:
+    for name, N, H, W, Cin, Cout, K, stride, pad, up in shapes:
         g = ops.fwd_geom(N, H, W, Cin, 0, up, K, K, stride, pad, Cout, 1)
         x = torch.randn(N, Cin, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
         w = (torch.randn(Cout, Cin, K, K, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
