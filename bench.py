@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--shape-report", default="", help="write the per-layer-shape conv timing table to this file")
     args = ap.parse_args()
 
     import council_gan_amd as cga
@@ -169,6 +170,8 @@ def main():
             torch.cuda.synchronize()
             prof = cga.hip.prof_collect()
             cga.hip.prof_enable(False)
+            if args.shape_report:
+                open(args.shape_report, "w").write(cga.hip.prof_report())
             kernels = {k: {"launches": c, "avg_us": round(1000.0 * ms / c, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                            "share_of_conv_time": 0.0} for k, (c, ms, fl) in prof.items()}
             tot_ms = sum(ms for _, ms, _ in prof.values())

@@ -16,7 +16,9 @@
 //   optional two-source channel concat); Wp is [Cout][T][Ct], k-contiguous.
 // GEMM view (wgrad):  dW[j][k] = sum_m dz[m][j] * A[m][k]   (split over m, deterministic reduce)
 #include <stddef.h>
+#include <map>
 #include <mutex>
+#include <string>
 #include <type_traits>
 #include <vector>
 #include "cg_common.h"
@@ -47,14 +49,34 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // The geometry struct is the FIRST kernel argument: read its tap table with a per-lane index straight
 // from the kernarg segment (constant address space).  Indexing the by-value struct dynamically
 // would make the compiler spill it to scratch.
-__device__ __forceinline__ int load_tap(int t) {
-    const int8_t* ka = (const int8_t*)__builtin_amdgcn_kernarg_segment_ptr();
+__device__ __forceinline__ int load_tap(int t, int geom_offset = 0) {
+    const int8_t* ka = (const int8_t*)__builtin_amdgcn_kernarg_segment_ptr() + geom_offset;
     const int dy = ka[offsetof(cg_conv_geom, dy) + t];
     const int dx = ka[offsetof(cg_conv_geom, dx) + t];
     return (dy & 0xffff) | (dx << 16);
 }
 
-__device__ __forceinline__ RowInfo decode_row(const cg_conv_geom& g, int m, int M, bool fwd_out) {
+// the scalar head of cg_conv_geom (same layout, without the tap tables)
+struct GeomS {
+    int32_t N, H, W, C1, C2, up, Ho, Wo, HoF, WoF, osy, osx, ooy, oox, stride, T, Cout, act;
+};
+static_assert(sizeof(GeomS) == offsetof(cg_conv_geom, dy), "GeomS mirrors the head of cg_conv_geom");
+
+// One launch of the pipelined kernel covers up to four geometry "classes" (blockIdx.y): the four output-parity
+// passes of a stride-2 data-gradient run as ONE grid.  A forward convolution is a batch of one.
+struct PipeClass {
+    cg_conv_geom g;
+    const float* w;
+    int32_t M, K, tiles_n, ntiles;
+    uint32_t w_bytes;
+    int32_t pad_;
+};
+struct PipeBatch {
+    PipeClass c[4];
+};
+
+template <class G>
+__device__ __forceinline__ RowInfo decode_row(const G& g, int m, int M, bool fwd_out) {
     const bool ok = m < M;
     const int mm = ok ? m : 0;
     const int hw = g.Ho * g.Wo;
@@ -71,7 +93,8 @@ __device__ __forceinline__ RowInfo decode_row(const cg_conv_geom& g, int m, int 
 }
 
 // one gathered input element / float4 (zero outside the image = ZeroPad2d)
-__device__ __forceinline__ bool tap_pixel(const cg_conv_geom& g, const RowInfo& ri, int tap_dydx, int& pix) {
+template <class G>
+__device__ __forceinline__ bool tap_pixel(const G& g, const RowInfo& ri, int tap_dydx, int& pix) {
     int dy = (int)(short)(tap_dydx & 0xffff);
     int dx = tap_dydx >> 16;
     int ly = ri.ly0 + dy, lx = ri.lx0 + dx;
@@ -301,8 +324,8 @@ __device__ __forceinline__ void dbg_stamp(int tile, int slot) {
 
 template <int BM, int BN, int WM, int WN, int PF, int ABL>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kernel(
-    cg_conv_geom g, const float* __restrict__ x1, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ y, int M, int K, int tiles_n, unsigned x_bytes, unsigned w_bytes) {
+    PipeBatch batch, const float* __restrict__ x1, const float* __restrict__ bias, float* __restrict__ y,
+    unsigned x_bytes) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN);
@@ -315,9 +338,27 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kern
     __shared__ RowInfo rows[BM];
     __shared__ int taps[CG_MAX_TAPS];
 
+    // this block's class: read straight from the kernarg segment (scalar loads; `batch` is the FIRST argument --
+    // indexing the by-value struct with blockIdx.y would make the compiler copy it to scratch)
+    typedef const __attribute__((address_space(4))) PipeClass* KernargClass;
+    const int cls_off = (int)blockIdx.y * (int)sizeof(PipeClass);
+    KernargClass pc = (KernargClass)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + cls_off);
+    const int ntiles = pc->ntiles;
+    if ((int)blockIdx.x >= ntiles) return;
+    GeomS g;
+    {
+        const __attribute__((address_space(4))) int32_t* gi = (const __attribute__((address_space(4))) int32_t*)pc;
+        int32_t* go = reinterpret_cast<int32_t*>(&g);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(GeomS) / 4); ++i) go[i] = gi[i];
+    }
+    const float* __restrict__ w = pc->w;
+    const int M = pc->M, K = pc->K, tiles_n = pc->tiles_n;
+    const unsigned w_bytes = pc->w_bytes;
+
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = xcd_remap(blockIdx.x, ntiles);
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
     const int Ct = g.C1;
@@ -332,7 +373,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kern
             cg_dbg[tile * CG_DBG_WORDS + 9] = blockIdx.x;
         }
     }
-    if (tid < g.T) taps[tid] = load_tap(tid);
+    if (tid < g.T) taps[tid] = load_tap(tid, cls_off);
     for (int r = tid; r < BM; r += NT) rows[r] = decode_row(g, m0 + r, M, true);
     __syncthreads();
 
@@ -736,6 +777,201 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_wgrad_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// weight-gradient kernel, software-pipelined (same schedule as conv_fwd_pipe_kernel):
+//   part[split][co][k] = sum_{m in split} dz[m][co] * A[m][k]
+// Restrictions (the launcher falls back to conv_wgrad_kernel otherwise): one source, every k-tile inside one
+// tap (C1 % BN == 0), Cout % 4 == 0, Ho*Wo and Wo powers of two (row decode by shifts, per thread, no LDS
+// round trip), operands addressable with 31-bit byte offsets.
+// LDS image: Ds[pos][co], Xs[pos][k] (position-major, as loaded).  MFMA tile i of a wave covers the
+// INTERLEAVED rows wm0 + l*TM + i (l = 0..31), so one lane's TM operands of a position are adjacent in LDS
+// and come with one ds_read_b64; likewise for the k columns when TN = 2.
+// ------------------------------------------------------------------------------------------
+template <int N>
+struct FVec;
+template <>
+struct FVec<1> {
+    float v[1];
+    __device__ __forceinline__ void load(const float* p) { v[0] = *p; }
+};
+template <>
+struct FVec<2> {
+    float v[2];
+    __device__ __forceinline__ void load(const float* p) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x;
+        v[1] = t.y;
+    }
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_wgrad_pipe_kernel(
+    cg_conv_geom g, const float* __restrict__ x1, const float* __restrict__ dz, float* __restrict__ out, int M, int K,
+    int tiles_n, int slices_per_split, int want_bias, int lg_hw, int lg_wo, unsigned x_bytes, unsigned dz_bytes) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int NW = (BM / WM) * (BN / WN);
+    constexpr int NT = NW * 64;
+    constexpr int BP = 32;  // output positions per K-slice
+    constexpr int D_CH = BM / 4, D_RP = NT / D_CH, D_V4 = BP / D_RP;
+    constexpr int X_CH = BN / 4, X_RP = NT / X_CH, X_V4 = BP / X_RP;
+    static_assert(TM <= 2 && TN <= 2, "wave tile at most 64 x 64");
+    static_assert(NT % D_CH == 0 && NT % X_CH == 0 && D_V4 >= 1 && X_V4 >= 1 && BP % D_RP == 0 && BP % X_RP == 0,
+                  "tile / loader mismatch");
+    __shared__ __attribute__((aligned(16))) float Ds[2][BP * BM];
+    __shared__ __attribute__((aligned(16))) float Xs[2][BP * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int tile = blockIdx.x;
+    const int co0 = (tile / tiles_n) * BM;
+    const int j0 = (tile % tiles_n) * BN;
+    const int Ct = g.C1;
+    const int split = blockIdx.z;
+    const int nslices_total = (M + BP - 1) / BP;
+    const int s_begin = split * slices_per_split;
+    const int s_end = min(s_begin + slices_per_split, nslices_total);
+    const int nk = s_end - s_begin;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x1, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (int)dz_bytes, 0x00020000);
+
+    // this block's k-tile lies inside ONE tap: (dy, dx) and the channel offset are block constants
+    const int tap = j0 / Ct;
+    const int td = load_tap(tap);
+    const int dy = (int)(short)(td & 0xffff), dx = td >> 16;
+    const int d_ch = tid % D_CH, d_r0 = tid / D_CH;
+    const int x_ch = tid % X_CH, x_r0 = tid / X_CH;
+    const unsigned d_col = (unsigned)(co0 + d_ch * 4);
+    const unsigned d_oob = d_col < (unsigned)g.Cout ? 0u : CG_OOB;
+    const unsigned x_col = (unsigned)(j0 - tap * Ct + x_ch * 4);
+    const int Hl = g.H << g.up, Wl = g.W << g.up;
+    const int hw_mask = (1 << lg_hw) - 1, wo_mask = (1 << lg_wo) - 1;
+    const int img = g.H * g.W;
+
+    float4 dv[D_V4], xv[X_V4];
+    int ld_s = s_begin;  // slice the next load_tile() fetches (clamped to the last slice of this split)
+    auto load_tile = [&]() {
+        const int mb = ld_s * BP;
+#pragma unroll
+        for (int i = 0; i < D_V4; ++i) {
+            const int m = mb + d_r0 + D_RP * i;
+            dv[i] = buf_load4(dr, ((((unsigned)m * (unsigned)g.Cout) + d_col) << 2) | d_oob | (m < M ? 0u : CG_OOB));
+        }
+#pragma unroll
+        for (int i = 0; i < X_V4; ++i) {
+            const int m = mb + x_r0 + X_RP * i;
+            const int n = m >> lg_hw, rem = m & hw_mask;
+            const int ly = (rem >> lg_wo) * g.stride + dy, lx = (rem & wo_mask) * g.stride + dx;
+            const bool ok = m < M && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
+            const unsigned pix = (unsigned)(n * img + (ly >> g.up) * g.W + (lx >> g.up));
+            xv[i] = buf_load4(xr, ((pix * (unsigned)Ct + x_col) << 2) | (ok ? 0u : CG_OOB));
+        }
+        if (ld_s + 1 < s_end) ++ld_s;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < D_V4; ++i) *reinterpret_cast<float4*>(&Ds[buf][(d_r0 + D_RP * i) * BM + d_ch * 4]) = dv[i];
+#pragma unroll
+        for (int i = 0; i < X_V4; ++i) *reinterpret_cast<float4*>(&Xs[buf][(x_r0 + X_RP * i) * BN + x_ch * 4]) = xv[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int a_off = lh * BM + wm0 + l31 * TM, b_off = lh * BN + wn0 + l31 * TN;
+
+    // fragment of k-step group grp (8 positions = 4 MFMA k-steps): lane (l31, lh) takes position 8*grp + 2*q + lh
+    auto read_frag = [&](int buf, int grp, FVec<TM>(&a)[4], FVec<TN>(&b)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q].load(&Ds[buf][a_off + (grp * 8 + 2 * q) * BM]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q].load(&Xs[buf][b_off + (grp * 8 + 2 * q) * BN]);
+    };
+    auto mma = [&](const FVec<TM>(&a)[4], const FVec<TN>(&b)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].v[i], b[q].v[j], acc[i][j], 0, 0, 0);
+    };
+    auto group_order = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);            // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);  // MFMA
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // bias gradient = column sums of dz: the first k-tile of every co-tile adds up the dz tile it stages anyway
+    const bool do_bias = want_bias && (tile % tiles_n == 0) && tid < BM;
+    float bsum = 0.f;
+
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    FVec<TM> a0[4], a1[4];
+    FVec<TN> b0[4], b1[4];
+    if (nk > 0) {
+        load_tile();
+        store_tile(0);
+        load_tile();
+        __syncthreads();
+        read_frag(0, 0, a0, b0);
+
+        auto slice = [&](auto cur_c) {
+            constexpr int CUR = decltype(cur_c)::value;
+            store_tile(CUR ^ 1);
+            load_tile();
+            if (do_bias) {
+#pragma unroll 8
+                for (int p = 0; p < BP; ++p) bsum += Ds[CUR][p * BM + tid];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag(CUR, 1, a1, b1);
+            mma(a0, b0);
+            group_order();
+            read_frag(CUR, 2, a0, b0);
+            mma(a1, b1);
+            group_order();
+            read_frag(CUR, 3, a1, b1);
+            mma(a0, b0);
+            group_order();
+            __syncthreads();
+            read_frag(CUR ^ 1, 0, a0, b0);
+            mma(a1, b1);
+            group_order();
+        };
+        for (int kt = 0; kt + 1 < nk; kt += 2) {
+            slice(I0());
+            slice(I1());
+        }
+        if (nk & 1) slice(I0());
+    }
+
+    // partial layout per split: [Cout*K weight partials | Cout bias partials]
+    float* dst = out + (size_t)split * ((size_t)g.Cout * K + g.Cout);
+    if (do_bias && co0 + tid < g.Cout) dst[(size_t)g.Cout * K + co0 + tid] = bsum;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = j0 + wn0 + l31 * TN + j;
+        if (col >= K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + wm0 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * TM + i;
+                if (row < g.Cout) dst[(size_t)row * K + col] = acc[i][j][r];
+            }
+    }
+}
+
 // dw[i] (+)= sum_s part[s][i] for the Cout*K weight partials, dbias[c] (+)= sum_s part[s][Cout*K + c]
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dbias,
                                      size_t nw, int nb, int splits, int accumulate) {
@@ -748,16 +984,29 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
     *dst = s;
 }
 
-struct TapMap {
-    int32_t t[CG_MAX_TAPS];
+// Weight re-layout for the data-gradient passes.  Entry z of the table moves one tap:
+//   out[dst_base[z] + (ci * dst_T[z] + dst_tc[z]) * Cout + co] = w[(co * T + src_tap[z]) * Cin + ci0 + ci]
+// (one 32x32 LDS-tiled transpose per tap and 32x32 (ci, co) patch)
+struct TransTable {
+    int32_t src_tap[CG_MAX_TAPS];
+    int32_t dst_base[CG_MAX_TAPS];
+    int32_t dst_tc[CG_MAX_TAPS];
+    int32_t dst_T[CG_MAX_TAPS];
 };
-// out[ci - ci0][tc][co] = w[co][tapmap[tc]][ci]; 32x32 LDS-tiled transpose per tap
+struct TransArgs {  // the kernel's kernarg layout (for the offset of the table)
+    const float* w;
+    float* out;
+    int32_t Cout, T, Cin, ci0, nci;
+    TransTable tt;
+};
 __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ out,
-                                                               int Cout, int T, int Cin, int ci0, int nci, TapMap tm,
-                                                               int Tc) {
+                                                               int Cout, int T, int Cin, int ci0, int nci, TransTable tt) {
     __shared__ float tile[32][33];
-    const int tc = blockIdx.z;
-    const int tap = tm.t[tc];
+    typedef const __attribute__((address_space(4))) int32_t* KI;
+    KI tab = (KI)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                  offsetof(TransArgs, tt));
+    const int z = blockIdx.z;
+    const int tap = tab[z], base = tab[CG_MAX_TAPS + z], tc = tab[2 * CG_MAX_TAPS + z], Tc = tab[3 * CG_MAX_TAPS + z];
     const int cib = blockIdx.x * 32, cob = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     for (int r = ty; r < 32; r += 8) {
@@ -767,7 +1016,7 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         int ci = cib + r, co = cob + tx;
-        if (ci < nci && co < Cout) out[((size_t)ci * Tc + tc) * Cout + co] = tile[tx][r];
+        if (ci < nci && co < Cout) out[(size_t)base + ((size_t)ci * Tc + tc) * Cout + co] = tile[tx][r];
     }
 }
 
@@ -776,7 +1025,9 @@ struct ProfRec {
     int slot;
     double flops;
     hipEvent_t e0, e1;
+    char key[96];
 };
+std::string prof_report;
 std::mutex prof_mu;
 bool prof_on = false;
 std::vector<ProfRec> prof_recs;
@@ -796,20 +1047,27 @@ struct ProfScope {
     bool active = false;
     ProfRec rec;
     hipStream_t st;
-    ProfScope(int family, int bm, int bn, bool fast, double flops, hipStream_t s) : st(s) {
+    ProfScope(int family, int bm, int bn, bool fast, double flops, hipStream_t s, const cg_conv_geom* g = nullptr,
+              int ncls = 1)
+        : st(s) {
         if (!prof_on) return;
         active = true;
+        rec.key[0] = 0;
+        if (g)
+            snprintf(rec.key, sizeof(rec.key), "f%d %3dx%-3d N%-2d %3dx%-3d C%-3d->%-3d T%-2d s%d u%d out%dx%d x%d", family, bm,
+                     bn, g->N, g->H, g->W, g->C1 + g->C2, g->Cout, g->T, g->stride, g->up, g->Ho, g->Wo, ncls);
         rec.slot = family * 16 + tile_id(bm, bn) * 2 + (fast ? 1 : 0);
         rec.flops = flops;
-        static const char* const fam[3] = {"conv_fwd_kernel", "conv_wgrad_kernel", "conv_fwd_pipe_kernel"};
+        static const char* const fam[4] = {"conv_fwd_kernel", "conv_wgrad_kernel", "conv_fwd_pipe_kernel",
+                                           "conv_wgrad_pipe_kernel"};
         snprintf(prof_names[rec.slot], sizeof(prof_names[0]), "%s<%d,%d,%s>", fam[family], bm, bn, fast ? "fast" : "generic");
-        hipEventCreate(&rec.e0);
-        hipEventCreate(&rec.e1);
-        hipEventRecord(rec.e0, st);
+        (void)hipEventCreate(&rec.e0);
+        (void)hipEventCreate(&rec.e1);
+        (void)hipEventRecord(rec.e0, st);
     }
     ~ProfScope() {
         if (!active) return;
-        hipEventRecord(rec.e1, st);
+        (void)hipEventRecord(rec.e1, st);
         std::lock_guard<std::mutex> lk(prof_mu);
         prof_recs.push_back(rec);
     }
@@ -833,7 +1091,7 @@ int launch_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const fl
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (g->Cout + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n), block(NT);
-    ProfScope prof(0, BM, BN, fast, 2.0 * (double)M * (double)g->Cout * (double)K, st);
+    ProfScope prof(0, BM, BN, fast, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
     if (fast)
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true, STAGES>), grid, block, 0, st, *g, x1, x2, w, bias, y, M,
                            K, tiles_n);
@@ -845,18 +1103,51 @@ int launch_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const fl
 }
 
 template <int BM, int BN, int WM, int WN, int PF = 1, int ABL = 0>
-int launch_fwd_pipe(const cg_conv_geom* g, const float* x1, const float* w, const float* bias, float* y, int M, int K,
-                    hipStream_t st) {
+int launch_pipe_batch(PipeBatch& b, int ncls, const float* x1, const float* bias, float* y, unsigned x_bytes, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (g->Cout + BN - 1) / BN;
-    const unsigned x_bytes = (unsigned)((size_t)g->N * g->H * g->W * g->C1 * sizeof(float));
-    const unsigned w_bytes = (unsigned)((size_t)g->Cout * K * sizeof(float));
-    dim3 grid(tiles_m * tiles_n), block(NT);
-    ProfScope prof(2, BM, BN, true, 2.0 * (double)M * (double)g->Cout * (double)K, st);
-    hipLaunchKernelGGL((conv_fwd_pipe_kernel<BM, BN, WM, WN, PF, ABL>), grid, block, 0, st, *g, x1, w, bias, y, M, K, tiles_n,
-                       x_bytes, w_bytes);
+    int max_tiles = 0;
+    double flops = 0.0;
+    for (int c = 0; c < ncls; ++c) {
+        PipeClass& pc = b.c[c];
+        pc.tiles_n = (pc.g.Cout + BN - 1) / BN;
+        pc.ntiles = ((pc.M + BM - 1) / BM) * pc.tiles_n;
+        if (pc.ntiles > max_tiles) max_tiles = pc.ntiles;
+        flops += 2.0 * (double)pc.M * (double)pc.g.Cout * (double)pc.K;
+    }
+    for (int c = ncls; c < 4; ++c) b.c[c].ntiles = 0;
+    dim3 grid(max_tiles, ncls), block(NT);
+    ProfScope prof(2, BM, BN, true, flops, st, &b.c[0].g, ncls);
+    hipLaunchKernelGGL((conv_fwd_pipe_kernel<BM, BN, WM, WN, PF, ABL>), grid, block, 0, st, b, x1, bias, y, x_bytes);
     CG_LAUNCH_CHECK("conv_fwd_pipe_kernel");
     return CG_OK;
+}
+
+int launch_pipe_cfg(int cfg, PipeBatch& b, int ncls, const float* x1, const float* bias, float* y, unsigned x_bytes,
+                    hipStream_t st) {
+    switch (cfg) {
+        case 20: return launch_pipe_batch<128, 128, 64, 32>(b, ncls, x1, bias, y, x_bytes, st);  // 8 waves
+        case 21: return launch_pipe_batch<128, 128, 64, 64>(b, ncls, x1, bias, y, x_bytes, st);  // 4 waves
+        case 22: return launch_pipe_batch<128, 64, 64, 32>(b, ncls, x1, bias, y, x_bytes, st);   // 4 waves
+        case 23: return launch_pipe_batch<64, 64, 32, 32>(b, ncls, x1, bias, y, x_bytes, st);    // 4 waves
+        case 24: return launch_pipe_batch<256, 128, 64, 64>(b, ncls, x1, bias, y, x_bytes, st);  // 8 waves
+        case 25: return launch_pipe_batch<128, 64, 32, 32>(b, ncls, x1, bias, y, x_bytes, st);   // 8 waves
+        case 26: return launch_pipe_batch<64, 128, 32, 64>(b, ncls, x1, bias, y, x_bytes, st);   // 4 waves
+        case 27: return launch_pipe_batch<128, 128, 64, 32, 2>(b, ncls, x1, bias, y, x_bytes, st);     // prefetch 2
+        case 28: return launch_pipe_batch<128, 128, 64, 32, 1, 1>(b, ncls, x1, bias, y, x_bytes, st);  // ablation
+        case 29: return launch_pipe_batch<128, 128, 64, 32, 1, 2>(b, ncls, x1, bias, y, x_bytes, st);  // ablation
+        case 30: return launch_pipe_batch<128, 128, 64, 64, 2>(b, ncls, x1, bias, y, x_bytes, st);     // 4 waves, prefetch 2
+        case 31: return launch_pipe_batch<128, 128, 64, 32, 1, 3>(b, ncls, x1, bias, y, x_bytes, st);  // timing probe
+        default: return cg_set_error(CG_ERR_ARG, "pipelined conv: unknown tile configuration %d", cfg);
+    }
+}
+
+void fill_class(PipeClass& pc, const cg_conv_geom* g, const float* w) {
+    pc.g = *g;
+    pc.w = w;
+    pc.M = g->N * g->Ho * g->Wo;
+    pc.K = g->T * g->C1;
+    pc.w_bytes = (unsigned)((size_t)g->Cout * pc.K * sizeof(float));
+    pc.pad_ = 0;
 }
 
 // the pipelined kernel needs: one source, channels a multiple of BK, operands addressable with 31-bit byte offsets
@@ -888,22 +1179,12 @@ int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float*
         case 16: return launch_fwd<64, 128, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
         case 17: return launch_fwd<128, 128, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 16 waves
         case 18: return launch_fwd<256, 128, 64, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 16 waves
-        case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31:
+        case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: {
             if (!pipe_ok(g, K)) return cg_set_error(CG_ERR_ARG, "conv forward: configuration %d needs the pipelined path", cfg);
-            switch (cfg) {
-                case 20: return launch_fwd_pipe<128, 128, 64, 32>(g, x1, w, bias, y, M, K, st);  // 8 waves
-                case 21: return launch_fwd_pipe<128, 128, 64, 64>(g, x1, w, bias, y, M, K, st);  // 4 waves
-                case 22: return launch_fwd_pipe<128, 64, 64, 32>(g, x1, w, bias, y, M, K, st);   // 4 waves
-                case 23: return launch_fwd_pipe<64, 64, 32, 32>(g, x1, w, bias, y, M, K, st);    // 4 waves
-                case 24: return launch_fwd_pipe<256, 128, 64, 64>(g, x1, w, bias, y, M, K, st);  // 8 waves
-                case 25: return launch_fwd_pipe<128, 64, 32, 32>(g, x1, w, bias, y, M, K, st);   // 8 waves
-                case 27: return launch_fwd_pipe<128, 128, 64, 32, 2>(g, x1, w, bias, y, M, K, st);     // prefetch 2
-                case 28: return launch_fwd_pipe<128, 128, 64, 32, 1, 1>(g, x1, w, bias, y, M, K, st);  // ablation
-                case 29: return launch_fwd_pipe<128, 128, 64, 32, 1, 2>(g, x1, w, bias, y, M, K, st);  // ablation
-                case 30: return launch_fwd_pipe<128, 128, 64, 64, 2>(g, x1, w, bias, y, M, K, st);     // 4 waves, prefetch 2
-                case 31: return launch_fwd_pipe<128, 128, 64, 32, 1, 3>(g, x1, w, bias, y, M, K, st);  // timing probe
-                default: return launch_fwd_pipe<64, 128, 32, 64>(g, x1, w, bias, y, M, K, st);   // 4 waves
-            }
+            PipeBatch b;
+            fill_class(b.c[0], g, w);
+            return launch_pipe_cfg(cfg, b, 1, x1, bias, y, (unsigned)((size_t)g->N * g->H * g->W * g->C1 * sizeof(float)), st);
+        }
         default: return cg_set_error(CG_ERR_ARG, "conv forward: unknown tile configuration %d", cfg);
     }
 }
@@ -924,6 +1205,8 @@ int pick_fwd_cfg(const cg_conv_geom* g, int M, bool pipe) {
     }
     return 2;
 }
+
+bool cg_wgrad_force_legacy = false;  // A/B switch (cg_conv2d_wgrad_legacy)
 
 struct WgradPlan {
     int bm, bn;
@@ -956,7 +1239,7 @@ WgradPlan plan_wgrad(const cg_conv_geom* g) {
     p.tiles_n = (K + p.bn - 1) / p.bn;
     const int slices = (M + 31) / 32;
     const int tiles = p.tiles_m * p.tiles_n;
-    int want = (2 * 256 + tiles - 1) / tiles;          // ~2 blocks per CU
+    int want = (2 * 256) / tiles;                      // two co-resident blocks per CU, and no partial second round
     int max_by_work = slices / 8 > 0 ? slices / 8 : 1; // >= 8 slices (256 positions) per split
     int s = want < max_by_work ? want : max_by_work;
     if (s < 1) s = 1;
@@ -970,7 +1253,7 @@ template <int BM, int BN, int WM, int WN>
 int launch_wgrad(const cg_conv_geom* g, const WgradPlan& p, const float* x1, const float* x2, const float* dz,
                  float* out, int M, int K, int want_bias, hipStream_t st) {
     dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits), block((BM / WM) * (BN / WN) * 64);
-    ProfScope prof(1, BM, BN, p.fast, 2.0 * (double)M * (double)g->Cout * (double)K, st);
+    ProfScope prof(1, BM, BN, p.fast, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
     if (p.fast)
         hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, *g, x1, x2, dz, out, M, K,
                            p.tiles_n, p.slices_per_split, want_bias);
@@ -978,6 +1261,36 @@ int launch_wgrad(const cg_conv_geom* g, const WgradPlan& p, const float* x1, con
         hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, false>), grid, block, 0, st, *g, x1, x2, dz, out, M, K,
                            p.tiles_n, p.slices_per_split, want_bias);
     CG_LAUNCH_CHECK("conv_wgrad_kernel");
+    return CG_OK;
+}
+
+int ilog2_exact(int v) {  // log2 of a power of two, -1 otherwise
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+bool wgrad_pipe_ok(const cg_conv_geom* g, const WgradPlan& p, int M) {
+    if (!p.fast || g->C2 != 0 || (g->Cout & 3)) return false;
+    if (ilog2_exact(g->Ho * g->Wo) < 0 || ilog2_exact(g->Wo) < 0) return false;
+    if (!((p.bm == 128 && p.bn == 128) || (p.bm == 128 && p.bn == 64) || (p.bm == 64 && p.bn == 64) ||
+          (p.bm == 64 && p.bn == 128)))
+        return false;
+    return (size_t)g->N * g->H * g->W * g->C1 * sizeof(float) < (size_t)CG_OOB &&
+           (size_t)M * g->Cout * sizeof(float) < (size_t)CG_OOB;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_wgrad_pipe(const cg_conv_geom* g, const WgradPlan& p, const float* x1, const float* dz, float* out, int M, int K,
+                      int want_bias, hipStream_t st) {
+    dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits), block((BM / WM) * (BN / WN) * 64);
+    ProfScope prof(3, BM, BN, true, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
+    hipLaunchKernelGGL((conv_wgrad_pipe_kernel<BM, BN, WM, WN>), grid, block, 0, st, *g, x1, dz, out, M, K, p.tiles_n,
+                       p.slices_per_split, want_bias, ilog2_exact(g->Ho * g->Wo), ilog2_exact(g->Wo),
+                       (unsigned)((size_t)g->N * g->H * g->W * g->C1 * sizeof(float)),
+                       (unsigned)((size_t)M * g->Cout * sizeof(float)));
+    CG_LAUNCH_CHECK("conv_wgrad_pipe_kernel");
     return CG_OK;
 }
 
@@ -1030,7 +1343,14 @@ extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const flo
     float* part = (float*)ws;
     const int want_bias = dbias != nullptr;
 #define WG(BM_, BN_, WM_, WN_) rc = launch_wgrad<BM_, BN_, WM_, WN_>(g, p, x1, x2, dz, part, M, K, want_bias, st)
-    if (p.bm == 128 && p.bn == 128) WG(128, 128, 64, 32);   // 8 waves
+#define WGP(BM_, BN_, WM_, WN_) rc = launch_wgrad_pipe<BM_, BN_, WM_, WN_>(g, p, x1, dz, part, M, K, want_bias, st)
+    if (wgrad_pipe_ok(g, p, M) && !cg_wgrad_force_legacy) {
+        if (p.bm == 128 && p.bn == 128) WGP(128, 128, 64, 32);   // 8 waves
+        else if (p.bm == 128 && p.bn == 64) WGP(128, 64, 64, 32);
+        else if (p.bm == 64 && p.bn == 64) WGP(64, 64, 32, 32);
+        else WGP(64, 128, 32, 64);
+    }
+    else if (p.bm == 128 && p.bn == 128) WG(128, 128, 64, 32);   // 8 waves
     else if (p.bm == 128 && p.bn == 64) WG(128, 64, 64, 32);
     else if (p.bm == 128 && p.bn == 32) WG(128, 32, 32, 32);
     else if (p.bm == 64 && p.bn == 128) WG(64, 128, 32, 64);
@@ -1038,6 +1358,7 @@ extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const flo
     else if (p.bm == 32 && p.bn == 128) WG(32, 128, 32, 32);
     else return cg_set_error(CG_ERR_ARG, "cg_conv2d_wgrad: no tile for %dx%d", p.bm, p.bn);
 #undef WG
+#undef WGP
     if (rc) return rc;
     const size_t nw = (size_t)g->Cout * K;
     const size_t n = nw + (want_bias ? g->Cout : 0);
@@ -1047,20 +1368,137 @@ extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const flo
     return CG_OK;
 }
 
+extern "C" int cg_conv2d_wgrad_legacy(int on) {
+    cg_wgrad_force_legacy = on != 0;
+    return CG_OK;
+}
+
+static int launch_transpose(const float* w, float* out, int Cout, int T, int Cin, int ci0, int nci, const TransTable& tt,
+                            int nz, hipStream_t st) {
+    dim3 grid(cg_div_up(nci, 32), cg_div_up(Cout, 32), nz);
+    hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, st, w, out, Cout, T, Cin, ci0, nci, tt);
+    CG_LAUNCH_CHECK("weight_transpose_kernel");
+    return CG_OK;
+}
+
 extern "C" int cg_weight_transpose(const float* w, float* out, int Cout, int T, int Cin, int ci0, int nci,
                                    const int32_t* tapmap_host, int Tc, cg_stream_t stream) {
     CG_CHECK_ARG(w && out && tapmap_host, "cg_weight_transpose: null pointer");
     CG_CHECK_ARG(Tc >= 1 && Tc <= CG_MAX_TAPS && T >= 1 && ci0 >= 0 && nci >= 1 && ci0 + nci <= Cin,
                  "cg_weight_transpose: bad sizes");
-    TapMap tm;
-    memset(&tm, 0, sizeof(tm));
+    TransTable tt;
+    memset(&tt, 0, sizeof(tt));
     for (int i = 0; i < Tc; ++i) {
         CG_CHECK_ARG(tapmap_host[i] >= 0 && tapmap_host[i] < T, "cg_weight_transpose: tap %d out of range", tapmap_host[i]);
-        tm.t[i] = tapmap_host[i];
+        tt.src_tap[i] = tapmap_host[i];
+        tt.dst_base[i] = 0;
+        tt.dst_tc[i] = i;
+        tt.dst_T[i] = Tc;
     }
-    dim3 grid(cg_div_up(nci, 32), cg_div_up(Cout, 32), Tc);
-    hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, cg_s(stream), w, out, Cout, T, Cin, ci0, nci, tm, Tc);
-    CG_LAUNCH_CHECK("weight_transpose_kernel");
+    return launch_transpose(w, out, Cout, T, Cin, ci0, nci, tt, Tc, cg_s(stream));
+}
+
+// ---- data gradient of a convolution -------------------------------------------------------------
+// dx[ly][lx] = sum over taps t and output positions with  oy*stride + dy[t] == ly  of  dz[oy][ox] * W[t].
+// Per output-parity class (ph, pw) = (ly % stride, lx % stride) this is a stride-1 convolution OVER dz with the taps
+// t for which stride | (ph - dy[t]), at offsets (ph - dy[t]) / stride, and with transposed weights; the classes
+// interleave into dx through the strided epilogue.  All classes of a layer run as ONE launch (blockIdx.y).
+namespace {
+struct DgradPlan {
+    int ncls;
+    cg_conv_geom cg[CG_MAX_TAPS];  // at most stride^2 classes; only the first ncls are valid (<= 4 batched)
+    int tap_src[CG_MAX_TAPS][CG_MAX_TAPS];
+    size_t w_off[CG_MAX_TAPS];
+    size_t ws_floats;
+};
+inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+int plan_dgrad(const cg_conv_geom* g, int nci, DgradPlan& p) {
+    const int s = g->stride;
+    const int Hl = g->H << g->up, Wl = g->W << g->up;
+    CG_CHECK_ARG(s >= 1 && s * s <= CG_MAX_TAPS, "cg_conv2d_dgrad: stride %d not supported", s);
+    p.ncls = 0;
+    p.ws_floats = 0;
+    for (int ph = 0; ph < s; ++ph)
+        for (int pw = 0; pw < s; ++pw) {
+            const int Hc = (Hl - ph + s - 1) / s, Wc = (Wl - pw + s - 1) / s;
+            if (Hc <= 0 || Wc <= 0) continue;
+            cg_conv_geom& c = p.cg[p.ncls];
+            memset(&c, 0, sizeof(c));
+            int tc = 0;
+            for (int t = 0; t < g->T; ++t) {
+                const int ay = ph - g->dy[t], ax = pw - g->dx[t];
+                if (ay - floordiv(ay, s) * s != 0 || ax - floordiv(ax, s) * s != 0) continue;
+                c.dy[tc] = (int8_t)floordiv(ay, s);
+                c.dx[tc] = (int8_t)floordiv(ax, s);
+                p.tap_src[p.ncls][tc] = t;
+                ++tc;
+            }
+            CG_CHECK_ARG(tc > 0, "cg_conv2d_dgrad: input positions without a tap (stride > kernel size)");
+            c.N = g->N; c.H = g->Ho; c.W = g->Wo; c.C1 = g->Cout; c.C2 = 0; c.up = 0;
+            c.Ho = Hc; c.Wo = Wc; c.HoF = Hl; c.WoF = Wl;
+            c.osy = c.osx = s; c.ooy = ph; c.oox = pw;
+            c.stride = 1; c.T = tc; c.Cout = nci; c.act = CG_ACT_NONE;
+            p.w_off[p.ncls] = p.ws_floats;
+            p.ws_floats += (size_t)nci * tc * g->Cout;
+            ++p.ncls;
+        }
+    return CG_OK;
+}
+}  // namespace
+
+extern "C" size_t cg_conv2d_dgrad_workspace(const cg_conv_geom* g, int nci) {
+    if (!g || g->T < 1 || g->T > CG_MAX_TAPS || nci < 1) return 0;
+    return (size_t)g->T * nci * g->Cout * sizeof(float);   // every tap belongs to exactly one class
+}
+
+extern "C" int cg_conv2d_dgrad(const cg_conv_geom* g, const float* dz, const float* w, int ci0, int nci, float* dx,
+                               void* ws, size_t ws_bytes, cg_stream_t stream) {
+    int rc = validate_geom(g, "cg_conv2d_dgrad");
+    if (rc) return rc;
+    CG_CHECK_ARG(dz && w && dx, "cg_conv2d_dgrad: null pointer");
+    const int Cin = g->C1 + g->C2;
+    CG_CHECK_ARG(ci0 >= 0 && nci >= 1 && ci0 + nci <= Cin, "cg_conv2d_dgrad: channel range [%d, %d) outside %d", ci0, ci0 + nci, Cin);
+    if (!ws || ws_bytes < cg_conv2d_dgrad_workspace(g, nci))
+        return cg_set_error(CG_ERR_WORKSPACE, "cg_conv2d_dgrad: workspace too small");
+    static thread_local DgradPlan p;
+    rc = plan_dgrad(g, nci, p);
+    if (rc) return rc;
+    hipStream_t st = cg_s(stream);
+    float* wt = (float*)ws;
+    // one launch re-lays-out the weights of every class: wt_c[ci][tc][co]
+    TransTable tt;
+    memset(&tt, 0, sizeof(tt));
+    int nz = 0;
+    for (int c = 0; c < p.ncls; ++c)
+        for (int tc = 0; tc < p.cg[c].T; ++tc, ++nz) {
+            tt.src_tap[nz] = p.tap_src[c][tc];
+            tt.dst_base[nz] = (int32_t)p.w_off[c];
+            tt.dst_tc[nz] = tc;
+            tt.dst_T[nz] = p.cg[c].T;
+        }
+    CG_CHECK_ARG(p.ws_floats < (size_t)0x7fffffff, "cg_conv2d_dgrad: weight tensor too large");
+    rc = launch_transpose(w, wt, g->Cout, g->T, Cin, ci0, nci, tt, nz, st);
+    if (rc) return rc;
+    // batched pipelined launch when every class qualifies
+    bool pipe = p.ncls <= 4;
+    long m_total = 0;
+    for (int c = 0; c < p.ncls && pipe; ++c) {
+        pipe = pipe_ok(&p.cg[c], p.cg[c].T * p.cg[c].C1);
+        m_total += (long)p.cg[c].N * p.cg[c].Ho * p.cg[c].Wo;
+    }
+    if (pipe) {
+        PipeBatch b;
+        for (int c = 0; c < p.ncls; ++c) fill_class(b.c[c], &p.cg[c], wt + p.w_off[c]);
+        const int cfg = pick_fwd_cfg(&p.cg[0], (int)(m_total > 0x7fffffffL ? 0x7fffffffL : m_total), true);
+        if (cfg >= 20)
+            return launch_pipe_cfg(cfg, b, p.ncls, dz, nullptr, dx,
+                                   (unsigned)((size_t)g->N * g->Ho * g->Wo * g->Cout * sizeof(float)), st);
+    }
+    for (int c = 0; c < p.ncls; ++c) {
+        rc = cg_conv2d_fwd(&p.cg[c], dz, nullptr, wt + p.w_off[c], nullptr, dx, stream);
+        if (rc) return rc;
+    }
     return CG_OK;
 }
 
@@ -1085,19 +1523,34 @@ extern "C" int cg_prof_collect(int64_t* counts, double* ms, double* flops) {
         ms[i] = 0.0;
         flops[i] = 0.0;
     }
+    struct Agg { long n = 0; double ms = 0, fl = 0; };
+    std::map<std::string, Agg> by_shape;
     for (auto& r : prof_recs) {
-        hipEventSynchronize(r.e1);
+        (void)hipEventSynchronize(r.e1);
         float t = 0.f;
-        hipEventElapsedTime(&t, r.e0, r.e1);
+        (void)hipEventElapsedTime(&t, r.e0, r.e1);
         counts[r.slot] += 1;
         ms[r.slot] += (double)t;
         flops[r.slot] += r.flops;
-        hipEventDestroy(r.e0);
-        hipEventDestroy(r.e1);
+        Agg& a = by_shape[r.key];
+        a.n += 1;
+        a.ms += (double)t;
+        a.fl += r.flops;
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
     }
     prof_recs.clear();
+    prof_report.clear();
+    char line[192];
+    for (auto& kv : by_shape) {
+        snprintf(line, sizeof(line), "%-70s n=%4ld  %9.3f ms  avg %8.1f us  %6.1f TF\n", kv.first.c_str(), kv.second.n, kv.second.ms,
+                 1000.0 * kv.second.ms / kv.second.n, kv.second.ms > 0 ? kv.second.fl / (kv.second.ms * 1e9) : 0.0);
+        prof_report += line;
+    }
     return CG_OK;
 }
+
+extern "C" const char* cg_prof_report(void) { return prof_report.c_str(); }
 
 extern "C" const char* cg_prof_slot_name(int slot) {
     if (slot < 0 || slot >= CG_PROF_SLOTS) return "";

@@ -37,6 +37,9 @@ _SIGS = {
     "cg_conv2d_fwd_tile": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P]),
     "cg_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvGeom)]),
     "cg_conv2d_wgrad": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "cg_conv2d_wgrad_legacy": (c_int, [c_int]),
+    "cg_conv2d_dgrad_workspace": (c_size_t, [POINTER(ConvGeom), c_int]),
+    "cg_conv2d_dgrad": (c_int, [POINTER(ConvGeom), _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "cg_weight_transpose": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int32), c_int, _P]),
     "cg_act_fwd": (c_int, [_P, _P, c_size_t, c_int, _P]),
     "cg_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
@@ -74,6 +77,7 @@ _SIGS = {
     "cg_prof_enable": (c_int, [c_int]),
     "cg_prof_collect": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     "cg_prof_slot_name": (c_char_p, [c_int]),
+    "cg_prof_report": (c_char_p, []),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -136,7 +140,7 @@ def workspace(nbytes):
     return buf
 
 
-PROF_SLOTS = 48
+PROF_SLOTS = 64
 
 
 def prof_enable(on):
@@ -155,3 +159,8 @@ def prof_collect():
         if counts[i]:
             out[lib.cg_prof_slot_name(i).decode()] = (int(counts[i]), float(ms[i]), float(flops[i]))
     return out
+
+
+def prof_report():
+    """Per-layer-shape text table of the last prof_collect()."""
+    return load().cg_prof_report().decode()

@@ -82,31 +82,16 @@ def dgrad_classes(Hl, Wl, KH, KW, stride, pad):
     return out
 
 
-def conv_dgrad(dz, w, Cin_total, ci0, nci, KH, KW, stride, pad, H, W, up):
-    """dx (w.r.t. channels [ci0, ci0+nci) of the conv input) from dz [N,Cout,Ho,Wo]; runs the forward
-    implicit-GEMM kernel on dz with re-laid-out weights."""
+def conv_dgrad(g, dz, w, ci0, nci):
+    """dx (w.r.t. channels [ci0, ci0+nci) of the conv input) from dz [N,Cout,Ho,Wo].  `g` is the FORWARD geometry of
+    the layer; the library derives the output-parity classes of a strided conv (`dgrad_classes` above is the host
+    restatement the CPU tests check) and runs them as one launch of the forward implicit-GEMM kernel on dz."""
     lib = _lib()
-    N, Cout, Ho, Wo = dz.shape
-    Hl, Wl = H << up, W << up
-    dxl = empty_nhwc(N, nci, Hl, Wl, dz)
-    T = KH * KW
-    for ph, pw, Hc, Wc, taps in dgrad_classes(Hl, Wl, KH, KW, stride, pad):
-        if not taps:
-            raise NotImplementedError("stride > kernel size leaves input positions without taps")
-        Tc = len(taps)
-        wt = torch.empty(nci * Tc * Cout, dtype=torch.float32, device=dz.device)
-        tapmap = (ctypes.c_int32 * Tc)(*[t for t, _, _ in taps])
-        check(lib.cg_weight_transpose(ptr(w), ptr(wt), Cout, T, Cin_total, ci0, nci, tapmap, Tc, stream()),
-              "cg_weight_transpose")
-        g = ConvGeom()
-        g.N, g.H, g.W, g.C1, g.C2, g.up = N, Ho, Wo, Cout, 0, 0
-        g.Ho, g.Wo, g.HoF, g.WoF = Hc, Wc, Hl, Wl
-        g.osy = g.osx = stride
-        g.ooy, g.oox = ph, pw
-        g.stride, g.T, g.Cout, g.act = 1, Tc, nci, 0
-        for i, (_, dy, dx) in enumerate(taps):
-            g.dy[i], g.dx[i] = dy, dx
-        check(lib.cg_conv2d_fwd(byref(g), ptr(dz), None, ptr(wt), None, ptr(dxl), stream()), "cg_conv2d_fwd(dgrad)")
+    N, H, W, up = g.N, g.H, g.W, g.up
+    dxl = empty_nhwc(N, nci, H << up, W << up, dz)
+    ws = workspace(lib.cg_conv2d_dgrad_workspace(byref(g), nci))
+    check(lib.cg_conv2d_dgrad(byref(g), ptr(dz), ptr(w), ci0, nci, ptr(dxl), ptr(ws), ws.numel(), stream()),
+          "cg_conv2d_dgrad")
     if not up:
         return dxl
     dx = empty_nhwc(N, nci, H, W, dz)
@@ -165,12 +150,10 @@ class _Conv2d(torch.autograd.Function):
             check(lib.cg_conv2d_wgrad(byref(g), ptr(x), ptr(x2), ptr(dz), ptr(dw_t), ptr(db_t), acc, ptr(ws),
                                       ws.numel(), stream()), "cg_conv2d_wgrad")
         if ctx.needs_input_grad[0]:
-            N, C1, H, W = x.shape
-            dx = conv_dgrad(dz, w, w.shape[1], 0, C1, KH, KW, stride, pad, H, W, up)
+            dx = conv_dgrad(g, dz, w, 0, x.shape[1])
         dx2 = None
         if x2 is not None and ctx.needs_input_grad[1]:
-            N, C1, H, W = x.shape
-            dx2 = conv_dgrad(dz, w, w.shape[1], C1, x2.shape[1], KH, KW, stride, pad, H, W, up)
+            dx2 = conv_dgrad(g, dz, w, x.shape[1], x2.shape[1])
         return dx, dx2, dw, db, None, None, None, None, None, None
 
 

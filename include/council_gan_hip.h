@@ -82,6 +82,17 @@ size_t cg_conv2d_wgrad_workspace(const cg_conv_geom* g);
 int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const float* x2, const float* dz, float* dw,
                     float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream);
 
+/* dx (w.r.t. input channels [ci0, ci0+nci) of the convolution described by the FORWARD geometry g) from
+ * dz [N, Ho, Wo, Cout]; dx is the dense [N, H<<up, W<<up, nci] tensor at the resolution the taps see (a nearest-2x
+ * input is folded back by cg_upsample2x_bwd).  Weights are re-laid-out into `ws` (cg_conv2d_dgrad_workspace
+ * bytes) and the stride^2 output-parity passes run as one launch.  networks.py:513 (autograd of nn.Conv2d). */
+size_t cg_conv2d_dgrad_workspace(const cg_conv_geom* g, int nci);
+int cg_conv2d_dgrad(const cg_conv_geom* g, const float* dz, const float* w, int ci0, int nci, float* dx, void* ws,
+                    size_t ws_bytes, cg_stream_t stream);
+
+/* A/B switch: force the non-pipelined weight-gradient kernel (tuning / regression checks only). */
+int cg_conv2d_wgrad_legacy(int on);
+
 /* Weight re-layout for the data-gradient pass: out[ci - ci0][tc][co] = w[co][tapmap[tc]][ci],
  * ci in [ci0, ci0+nci).  w is [Cout][T][Cin]; out is [nci][Tc][Cout]. */
 int cg_weight_transpose(const float* w, float* out, int Cout, int T, int Cin, int ci0, int nci,
@@ -176,10 +187,12 @@ int cg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
  * HIP events recorded on the launch stream.  cg_prof_collect() synchronises them and returns, per
  * kernel slot (slot = kernel family * 16 + tile shape * 2 + fast-path flag; see cg_prof_slot_name),
  * launch count, total milliseconds and total algorithmic FLOPs (2*M*N*K of each launch). */
-#define CG_PROF_SLOTS 48
+#define CG_PROF_SLOTS 64
 int cg_prof_enable(int on);
 int cg_prof_collect(int64_t* counts, double* ms, double* flops);
 const char* cg_prof_slot_name(int slot);
+/* text table of the last cg_prof_collect(): one line per (kernel family, tile, layer shape) */
+const char* cg_prof_report(void);
 
 /* Timing probe (development aid): after a cg_conv2d_fwd_tile() launch with tile_cfg 31, 16 words per block --
  * {shader clock, 100 MHz wall clock} at kernel entry / loop start / loop end / exit, hardware id, block id. */

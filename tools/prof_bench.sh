@@ -1,0 +1,12 @@
+# rocprofv3 kernel-trace of the default bench; writes a text summary under gpurun_out/<tag>/
+TAG=${1:-prof}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+rocprofv3 --kernel-trace --stats -d $O/raw -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
+DB=$(find $O/raw -name "*.db" | head -1)
+python $R/tools/rocpd_summary.py $DB 70 > $O/kernel_stats.txt 2>&1
+rm -rf $O/raw
+head -75 $O/kernel_stats.txt
+cut -c1-300 $O/bench.json
