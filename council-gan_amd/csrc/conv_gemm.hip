@@ -325,7 +325,7 @@ __device__ __forceinline__ void dbg_stamp(int tile, int slot) {
 template <int BM, int BN, int WM, int WN, int PF, int ABL>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kernel(
     PipeBatch batch, const float* __restrict__ x1, const float* __restrict__ bias, float* __restrict__ y,
-    unsigned x_bytes) {
+    unsigned x_bytes, double* __restrict__ stats) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN);
@@ -542,9 +542,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kern
     }
     if constexpr (ABL == 3) dbg_stamp(tile, 2);
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // With `stats` (instance-norm fusion; the launcher guarantees M % BM == 0 and act == none) the block also emits
+    // {sum y, sum y^2} of its BM rows per output column, accumulated in fp64.
+    double cs[TN], cq[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
+        cs[j] = 0.0;
+        cq[j] = 0.0;
         const int col = n0 + wn0 + j * 32 + l31;
         if (col >= g.Cout) continue;
         const float bj = bias ? bias[col] : 0.f;
@@ -554,8 +559,38 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kern
             for (int r = 0; r < 16; ++r) {
                 const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const RowInfo ri = rows[row];
-                if (ri.base >= 0) y[(size_t)ri.out_off + col] = cg_apply_act(acc[i][j][r] + bj, g.act);
+                const float v = cg_apply_act(acc[i][j][r] + bj, g.act);
+                if (ri.base >= 0) y[(size_t)ri.out_off + col] = v;
+                if (stats) {
+                    cs[j] += (double)v;
+                    cq[j] += (double)v * (double)v;
+                }
             }
+        }
+    }
+    if (stats) {
+        constexpr int WAVES_M = BM / WM;
+        double* red = reinterpret_cast<double*>(&As[0][0]);   // [WAVES_M][BN][2], the operand buffers are free now
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const double a = cs[j] + __shfl_xor(cs[j], 32, 64), b = cq[j] + __shfl_xor(cq[j], 32, 64);
+            if (lh == 0) {
+                red[((wid / WAVES_N) * BN + wn0 + j * 32 + l31) * 2] = a;
+                red[((wid / WAVES_N) * BN + wn0 + j * 32 + l31) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.Cout) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int wmi = 0; wmi < WAVES_M; ++wmi) {
+                a += red[(wmi * BN + tid) * 2];
+                b += red[(wmi * BN + tid) * 2 + 1];
+            }
+            double* o = stats + ((size_t)(tile / tiles_n) * g.Cout + n0 + tid) * 2;
+            o[0] = a;
+            o[1] = b;
         }
     }
     if constexpr (ABL == 3) {
@@ -972,16 +1007,27 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_wgrad_pipe_ke
     }
 }
 
-// dw[i] (+)= sum_s part[s][i] for the Cout*K weight partials, dbias[c] (+)= sum_s part[s][Cout*K + c]
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dbias,
-                                     size_t nw, int nb, int splits, int accumulate) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// dw[i] (+)= sum_s part[s][i] for the Cout*K weight partials, dbias[c] (+)= sum_s part[s][Cout*K + c].
+// L lanes cooperate on one output element (lane j adds splits j, j+L, ...; fixed-order butterfly combine), so the
+// many-split / tiny-output layers (first convs: 512 splits of a 64x54 gradient) do not serialise 512 loads per thread.
+template <int L>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                            float* __restrict__ dbias, size_t nw, int nb, int splits,
+                                                            int accumulate) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = t / L;
+    const int j = (int)(t % L);
     const size_t stride = nw + (size_t)nb;
-    if (i >= nw + (dbias ? (size_t)nb : 0)) return;
-    float* dst = i < nw ? dw + i : dbias + (i - nw);
-    float s = accumulate ? *dst : 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(size_t)k * stride + i];
-    *dst = s;
+    const size_t n = nw + (dbias ? (size_t)nb : 0);
+    float s = 0.f;
+    if (i < n)
+        for (int k = j; k < splits; k += L) s += part[(size_t)k * stride + i];
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (i < n && j == 0) {
+        float* dst = i < nw ? dw + i : dbias + (i - nw);
+        *dst = accumulate ? *dst + s : s;
+    }
 }
 
 // Weight re-layout for the data-gradient passes.  Entry z of the table moves one tap:
@@ -1103,7 +1149,8 @@ int launch_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const fl
 }
 
 template <int BM, int BN, int WM, int WN, int PF = 1, int ABL = 0>
-int launch_pipe_batch(PipeBatch& b, int ncls, const float* x1, const float* bias, float* y, unsigned x_bytes, hipStream_t st) {
+int launch_pipe_batch(PipeBatch& b, int ncls, const float* x1, const float* bias, float* y, unsigned x_bytes, hipStream_t st,
+                      double* stats = nullptr, int* stats_rows = nullptr) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     int max_tiles = 0;
     double flops = 0.0;
@@ -1117,18 +1164,21 @@ int launch_pipe_batch(PipeBatch& b, int ncls, const float* x1, const float* bias
     for (int c = ncls; c < 4; ++c) b.c[c].ntiles = 0;
     dim3 grid(max_tiles, ncls), block(NT);
     ProfScope prof(2, BM, BN, true, flops, st, &b.c[0].g, ncls);
-    hipLaunchKernelGGL((conv_fwd_pipe_kernel<BM, BN, WM, WN, PF, ABL>), grid, block, 0, st, b, x1, bias, y, x_bytes);
+    if (stats_rows) *stats_rows = BM;
+    hipLaunchKernelGGL((conv_fwd_pipe_kernel<BM, BN, WM, WN, PF, ABL>), grid, block, 0, st, b, x1, bias, y, x_bytes, stats);
     CG_LAUNCH_CHECK("conv_fwd_pipe_kernel");
     return CG_OK;
 }
 
+int pipe_cfg_bm(int cfg) { return cfg == 23 || cfg == 26 ? 64 : (cfg == 24 ? 256 : 128); }
+
 int launch_pipe_cfg(int cfg, PipeBatch& b, int ncls, const float* x1, const float* bias, float* y, unsigned x_bytes,
-                    hipStream_t st) {
+                    hipStream_t st, double* stats = nullptr) {
     switch (cfg) {
-        case 20: return launch_pipe_batch<128, 128, 64, 32>(b, ncls, x1, bias, y, x_bytes, st);  // 8 waves
-        case 21: return launch_pipe_batch<128, 128, 64, 64>(b, ncls, x1, bias, y, x_bytes, st);  // 4 waves
-        case 22: return launch_pipe_batch<128, 64, 64, 32>(b, ncls, x1, bias, y, x_bytes, st);   // 4 waves
-        case 23: return launch_pipe_batch<64, 64, 32, 32>(b, ncls, x1, bias, y, x_bytes, st);    // 4 waves
+        case 20: return launch_pipe_batch<128, 128, 64, 32>(b, ncls, x1, bias, y, x_bytes, st, stats);  // 8 waves
+        case 21: return launch_pipe_batch<128, 128, 64, 64>(b, ncls, x1, bias, y, x_bytes, st, stats);  // 4 waves
+        case 22: return launch_pipe_batch<128, 64, 64, 32>(b, ncls, x1, bias, y, x_bytes, st, stats);   // 4 waves
+        case 23: return launch_pipe_batch<64, 64, 32, 32>(b, ncls, x1, bias, y, x_bytes, st, stats);    // 4 waves
         case 24: return launch_pipe_batch<256, 128, 64, 64>(b, ncls, x1, bias, y, x_bytes, st);  // 8 waves
         case 25: return launch_pipe_batch<128, 64, 32, 32>(b, ncls, x1, bias, y, x_bytes, st);   // 8 waves
         case 26: return launch_pipe_batch<64, 128, 32, 64>(b, ncls, x1, bias, y, x_bytes, st);   // 4 waves
@@ -1158,7 +1208,7 @@ bool pipe_ok(const cg_conv_geom* g, int K) {
 
 // tile configurations of the forward kernel (id -> BM, BN, WM, WN, STAGES)
 int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
-                   float* y, int M, int K, bool fast, hipStream_t st) {
+                   float* y, int M, int K, bool fast, hipStream_t st, double* stats = nullptr) {
     switch (cfg) {
         case 0: return launch_fwd<128, 128, 64, 64, 1>(g, x1, x2, w, bias, y, M, K, fast, st);
         case 1: return launch_fwd<128, 64, 64, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);
@@ -1183,7 +1233,8 @@ int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float*
             if (!pipe_ok(g, K)) return cg_set_error(CG_ERR_ARG, "conv forward: configuration %d needs the pipelined path", cfg);
             PipeBatch b;
             fill_class(b.c[0], g, w);
-            return launch_pipe_cfg(cfg, b, 1, x1, bias, y, (unsigned)((size_t)g->N * g->H * g->W * g->C1 * sizeof(float)), st);
+            return launch_pipe_cfg(cfg, b, 1, x1, bias, y, (unsigned)((size_t)g->N * g->H * g->W * g->C1 * sizeof(float)), st,
+                                   stats);
         }
         default: return cg_set_error(CG_ERR_ARG, "conv forward: unknown tile configuration %d", cfg);
     }
@@ -1243,7 +1294,7 @@ WgradPlan plan_wgrad(const cg_conv_geom* g) {
     int max_by_work = slices / 8 > 0 ? slices / 8 : 1; // >= 8 slices (256 positions) per split
     int s = want < max_by_work ? want : max_by_work;
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
+    if (s > 512) s = 512;
     p.slices_per_split = (slices + s - 1) / s;
     p.splits = (slices + p.slices_per_split - 1) / p.slices_per_split;
     return p;
@@ -1315,6 +1366,30 @@ extern "C" int cg_conv2d_fwd(const cg_conv_geom* g, const float* x1, const float
     return conv2d_fwd_impl(g, x1, x2, w, bias, y, -1, stream);
 }
 
+extern "C" int cg_conv2d_fwd_stats(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
+                                   const float* bias, float* y, double* stats, size_t stats_bytes, int* rows_per_partial,
+                                   cg_stream_t stream) {
+    int rc = validate_geom(g, "cg_conv2d_fwd_stats");
+    if (rc) return rc;
+    CG_CHECK_ARG(x1 && w && y && rows_per_partial, "cg_conv2d_fwd_stats: null pointer");
+    CG_CHECK_ARG(g->C2 == 0 || x2, "cg_conv2d_fwd_stats: C2 > 0 needs x2");
+    const int Ct = g->C1 + g->C2;
+    const int K = g->T * Ct;
+    const int M = g->N * g->Ho * g->Wo;
+    const bool fast = (g->C2 == 0) && (Ct % 32 == 0);
+    const int cfg = pick_fwd_cfg(g, M, fast && pipe_ok(g, K));
+    *rows_per_partial = 0;
+    double* st_ptr = nullptr;
+    if (cfg >= 20 && stats && g->act == CG_ACT_NONE && g->osy == 1 && g->osx == 1) {
+        const int bm = pipe_cfg_bm(cfg);
+        if ((g->Ho * g->Wo) % bm == 0 && stats_bytes >= (size_t)(M / bm) * g->Cout * 2 * sizeof(double)) {
+            st_ptr = stats;
+            *rows_per_partial = bm;
+        }
+    }
+    return launch_fwd_cfg(cfg, g, x1, x2, w, bias, y, M, K, fast, cg_s(stream), st_ptr);
+}
+
 extern "C" int cg_conv2d_fwd_tile(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
                                   const float* bias, float* y, int tile_cfg, cg_stream_t stream) {
     return conv2d_fwd_impl(g, x1, x2, w, bias, y, tile_cfg, stream);
@@ -1362,8 +1437,15 @@ extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const flo
     if (rc) return rc;
     const size_t nw = (size_t)g->Cout * K;
     const size_t n = nw + (want_bias ? g->Cout : 0);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cg_div_up(n, 256)), dim3(256), 0, st, (const float*)part, dw, dbias, nw,
-                       g->Cout, p.splits, accumulate);
+    if (p.splits >= 128)
+        hipLaunchKernelGGL(splitk_reduce_kernel<64>, dim3(cg_div_up(n * 64, 256)), dim3(256), 0, st, (const float*)part, dw,
+                           dbias, nw, g->Cout, p.splits, accumulate);
+    else if (p.splits >= 24)
+        hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(cg_div_up(n * 8, 256)), dim3(256), 0, st, (const float*)part, dw, dbias,
+                           nw, g->Cout, p.splits, accumulate);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cg_div_up(n, 256)), dim3(256), 0, st, (const float*)part, dw, dbias,
+                           nw, g->Cout, p.splits, accumulate);
     CG_LAUNCH_CHECK("splitk_reduce_kernel");
     return CG_OK;
 }

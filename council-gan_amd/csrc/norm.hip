@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int NC_SPLIT_ROWS = 256;  // rows (pixels) per block in the per-(n,c) reductions
+constexpr int NC_SPLIT_ROWS = 64;  // rows (pixels) per block in the per-(n,c) reductions
 
 __host__ __device__ inline int nc_splits(int HW) { return (HW + NC_SPLIT_ROWS - 1) / NC_SPLIT_ROWS; }
 
@@ -58,6 +58,32 @@ __global__ __launch_bounds__(256) void in_stats_final(const double* __restrict__
     if (lane == 0) {
         double m = a / HW;
         double var = b / HW - m * m;  // biased variance (batch_norm training / InstanceNorm2d)
+        if (var < 0.0) var = 0.0;
+        mean[i] = (float)m;
+        rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// statistics from the partials a convolution epilogue emitted (cg_conv2d_fwd_stats): part[((n*S + s)*C + c)*2 + {0,1}]
+// = {sum y, sum y^2} over rows [s*R, (s+1)*R) of sample n.  One wavefront per (n, c), lanes stride over s.
+__global__ __launch_bounds__(256) void in_stats_final_tiles(const double* __restrict__ part, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int NC, int C, int S, int HW,
+                                                            float eps) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= NC) return;
+    const int lane = threadIdx.x & 63;
+    const int n = i / C, c = i - n * C;
+    double a = 0.0, b = 0.0;
+    for (int s = lane; s < S; s += 64) {
+        const double* p = part + ((size_t)(n * S + s) * C + c) * 2;
+        a += p[0];
+        b += p[1];
+    }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (lane == 0) {
+        double m = a / HW;
+        double var = b / HW - m * m;
         if (var < 0.0) var = 0.0;
         mean[i] = (float)m;
         rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
@@ -188,6 +214,155 @@ __global__ __launch_bounds__(256) void in_bwd_apply(const float* __restrict__ dy
         const float dz = in_dz(dy[e], xh, g, bt, act);
         dx[e] = rs * g * (dz - s12[sc * 2] - xh * s12[sc * 2 + 1]);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Bandwidth-shaped variants (C % 4 == 0 and 256 % (C/4) == 0, i.e. every width of the shipped networks):
+// every thread owns ONE channel quad for its whole life, so mean / rstd / gamma / beta sit in registers, all index
+// arithmetic is 32-bit and loop-invariant, and every access is a 16-byte vector.  blockIdx.y = sample.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+struct Quad {
+    float m[4], r[4], g[4], b[4];
+};
+__device__ __forceinline__ Quad load_quad(const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                          int n, int C, int c, int gs) {
+    Quad q;
+    const float4 m = ld4(mean + n * C + c), r = ld4(rstd + n * C + c);
+    q.m[0] = m.x; q.m[1] = m.y; q.m[2] = m.z; q.m[3] = m.w;
+    q.r[0] = r.x; q.r[1] = r.y; q.r[2] = r.z; q.r[3] = r.w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // gamma / beta live inside the MLP output row: 4-byte aligned only
+        q.g[k] = gamma ? gamma[n * gs + c + k] : 1.f;
+        q.b[k] = gamma ? beta[n * gs + c + k] : 0.f;
+    }
+    return q;
+}
+
+// y = act((x - mean) * rstd * gamma + beta) + residual
+template <bool RES>
+__global__ __launch_bounds__(256) void in_apply_q(const float* __restrict__ x, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, const float* __restrict__ residual,
+                                                  float* __restrict__ y, int HW, int C, int act, int gs) {
+    const int n = blockIdx.y;
+    const int nq = HW * (C >> 2);                       // quads per sample
+    const int step = gridDim.x * 256;                   // multiple of C/4: the channel quad is loop-invariant
+    int i = blockIdx.x * 256 + threadIdx.x;
+    const int c = (i % (C >> 2)) << 2;
+    const Quad q = load_quad(mean, rstd, gamma, beta, n, C, c, gs);
+    const size_t base = (size_t)n * HW * C;
+    x += base; y += base;
+    if (RES) residual += base;
+    for (; i < nq; i += step) {
+        const float4 v = ld4(x + 4 * (size_t)i);
+        float4 rr;
+        if (RES) rr = ld4(residual + 4 * (size_t)i);
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = cg_apply_act((o[k] - q.m[k]) * q.r[k] * q.g[k] + q.b[k], act);
+        if (RES) { o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w; }
+        st4(y + 4 * (size_t)i, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+// the reference applies gamma as a multiplier of the normalised value: keep (x-m)*r first, then *g (same rounding
+// order as in_apply_kernel)
+
+// ws[((n*C + c)*S + s)*2 + {0,1}] = {sum dz, sum dz*xhat} over the rows of split s.  Block = (C/4) channel quads x
+// 256/(C/4) row lanes; each thread streams float4s of its quad down the rows.
+__global__ __launch_bounds__(256) void in_bwd_partial_q(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        double* __restrict__ ws, int HW, int C, int S, int rows_per_split,
+                                                        int act, int gs) {
+    __shared__ double red[256 * 8];
+    const int Q = C >> 2, RL = 256 / Q;
+    const int qi = threadIdx.x % Q, rl = threadIdx.x / Q;
+    const int n = blockIdx.y, s = blockIdx.x;
+    const int c = qi << 2;
+    const Quad q = load_quad(mean, rstd, gamma, beta, n, C, c, gs);
+    const int r0 = s * rows_per_split, r1 = min(r0 + rows_per_split, HW);
+    const size_t base = (size_t)n * HW * C + c;
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const float4 xv = ld4(x + base + (size_t)r * C), dv = ld4(dy + base + (size_t)r * C);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xs[k] - q.m[k]) * q.r[k];
+            const float dz = in_dz(ds[k], xh, q.g[k], q.b[k], act);
+            a[k] += (double)dz;
+            b[k] += (double)dz * (double)xh;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[threadIdx.x * 8 + k] = a[k];
+        red[threadIdx.x * 8 + 4 + k] = b[k];
+    }
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double sa = 0.0, sb = 0.0;
+            for (int j = 0; j < RL; ++j) {
+                sa += red[(j * Q + qi) * 8 + k];
+                sb += red[(j * Q + qi) * 8 + 4 + k];
+            }
+            double* o = ws + ((size_t)(n * C + c + k) * S + s) * 2;
+            o[0] = sa;
+            o[1] = sb;
+        }
+    }
+}
+
+// dx = rstd * gamma * (dz - S1/HW - xhat * S2/HW)
+__global__ __launch_bounds__(256) void in_bwd_apply_q(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ s12, float* __restrict__ dx, int HW, int C,
+                                                      int act, int gs) {
+    const int n = blockIdx.y;
+    const int nq = HW * (C >> 2);
+    const int step = gridDim.x * 256;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    const int c = (i % (C >> 2)) << 2;
+    const Quad q = load_quad(mean, rstd, gamma, beta, n, C, c, gs);
+    float s1[4], s2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        s1[k] = s12[(n * C + c + k) * 2];
+        s2[k] = s12[(n * C + c + k) * 2 + 1];
+    }
+    const size_t base = (size_t)n * HW * C;
+    x += base; dy += base; dx += base;
+    for (; i < nq; i += step) {
+        const float4 xv = ld4(x + 4 * (size_t)i), dv = ld4(dy + 4 * (size_t)i);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xs[k] - q.m[k]) * q.r[k];
+            const float dz = in_dz(ds[k], xh, q.g[k], q.b[k], act);
+            o[k] = q.r[k] * q.g[k] * (dz - s1[k] - xh * s2[k]);
+        }
+        st4(dx + 4 * (size_t)i, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+__host__ inline bool quad_ok(int C) { return (C & 3) == 0 && C >= 4 && (256 % (C >> 2)) == 0; }
+// blocks along x for the streaming kernels: enough to fill the chip, each thread keeps a few float4 in flight
+__host__ inline unsigned quad_grid(int HW, int C, int N) {
+    const long nq = (long)HW * (C >> 2);
+    long b = (nq + 256 * 4 - 1) / (256 * 4);      // ~4 float4 per thread
+    const long cap = (2048 + N - 1) / N;          // ~8 blocks per CU over all samples
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -352,13 +527,31 @@ extern "C" int cg_instnorm_stats(const float* x, int N, int HW, int C, float eps
     return CG_OK;
 }
 
+extern "C" int cg_instnorm_stats_from_partials(const double* part, int N, int HW, int C, int rows_per_partial, float eps,
+                                               float* mean, float* rstd, cg_stream_t stream) {
+    CG_CHECK_ARG(part && mean && rstd && N > 0 && HW > 0 && C > 0 && rows_per_partial > 0 && HW % rows_per_partial == 0,
+                 "cg_instnorm_stats_from_partials: bad args");
+    hipLaunchKernelGGL(in_stats_final_tiles, dim3(cg_div_up((size_t)N * C, 4)), dim3(256), 0, cg_s(stream), part, mean, rstd,
+                       N * C, C, HW / rows_per_partial, HW, eps);
+    CG_LAUNCH_CHECK("in_stats_final_tiles");
+    return CG_OK;
+}
+
 extern "C" int cg_instnorm_apply(const float* x, const float* mean, const float* rstd, const float* gamma,
                                  const float* beta, int gstride, const float* residual, float* y, int N, int HW, int C,
                                  int act, cg_stream_t stream) {
     CG_CHECK_ARG(x && mean && rstd && y && N > 0 && HW > 0 && C > 0, "cg_instnorm_apply: bad args");
     CG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "cg_instnorm_apply: gamma and beta go together");
     const size_t total = (size_t)N * HW * C;
-    if ((C & 3) == 0)
+    if (quad_ok(C) && (size_t)HW * C < (size_t)0x7fffffff) {
+        dim3 grid(quad_grid(HW, C, N), N);
+        if (residual)
+            hipLaunchKernelGGL((in_apply_q<true>), grid, dim3(256), 0, cg_s(stream), x, mean, rstd, gamma, beta, residual, y, HW,
+                               C, act, gstride);
+        else
+            hipLaunchKernelGGL((in_apply_q<false>), grid, dim3(256), 0, cg_s(stream), x, mean, rstd, gamma, beta, residual, y, HW,
+                               C, act, gstride);
+    } else if ((C & 3) == 0)
         hipLaunchKernelGGL((in_apply_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, cg_s(stream), x, mean, rstd,
                            gamma, beta, residual, y, total, HW, C, act, gstride);
     else
@@ -379,15 +572,24 @@ extern "C" int cg_instnorm_bwd(const float* dy, const float* x, const float* mea
     const int S = nc_splits(HW);
     double* part = (double*)ws;
     float* s12 = (float*)(part + (size_t)N * C * S * 2);
-    hipLaunchKernelGGL(in_bwd_partial, dim3(cg_div_up(C, 64), N, S), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma,
-                       beta, part, HW, C, S, act, gstride);
+    const bool quad = quad_ok(C) && (size_t)HW * C < (size_t)0x7fffffff;
+    if (quad)
+        hipLaunchKernelGGL(in_bwd_partial_q, dim3(S, N), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma, beta, part, HW, C,
+                           S, NC_SPLIT_ROWS, act, gstride);
+    else
+        hipLaunchKernelGGL(in_bwd_partial, dim3(cg_div_up(C, 64), N, S), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma,
+                           beta, part, HW, C, S, act, gstride);
     CG_LAUNCH_CHECK("in_bwd_partial");
     hipLaunchKernelGGL(in_bwd_final, dim3(cg_div_up((size_t)N * C, 4)), dim3(256), 0, cg_s(stream), (const double*)part,
                        s12, dgamma, dbeta, N * C, S, HW, C, gstride);
     CG_LAUNCH_CHECK("in_bwd_final");
     const size_t total = (size_t)N * HW * C;
-    hipLaunchKernelGGL(in_bwd_apply, dim3(ew_grid(total)), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma, beta,
-                       (const float*)s12, dx, total, HW, C, act, gstride);
+    if (quad)
+        hipLaunchKernelGGL(in_bwd_apply_q, dim3(quad_grid(HW, C, N), N), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma,
+                           beta, (const float*)s12, dx, HW, C, act, gstride);
+    else
+        hipLaunchKernelGGL(in_bwd_apply, dim3(ew_grid(total)), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma, beta,
+                           (const float*)s12, dx, total, HW, C, act, gstride);
     CG_LAUNCH_CHECK("in_bwd_apply");
     return CG_OK;
 }

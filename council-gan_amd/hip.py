@@ -34,6 +34,8 @@ _SIGS = {
     "cg_last_error": (c_char_p, []),
     "cg_version": (c_int, []),
     "cg_conv2d_fwd": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P]),
+    "cg_conv2d_fwd_stats": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_size_t, POINTER(c_int), _P]),
+    "cg_instnorm_stats_from_partials": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "cg_conv2d_fwd_tile": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P]),
     "cg_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvGeom)]),
     "cg_conv2d_wgrad": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
@@ -127,10 +129,11 @@ def ptr(t):
 _ws_cache = {}
 
 
-def workspace(nbytes):
+def workspace(nbytes, slot=0):
     """Per-device scratch owned by PyTorch's caching allocator; kernels on one stream are ordered,
-    so one buffer per device is shared by every op."""
-    dev = torch.cuda.current_device()
+    so one buffer per device (and slot) is shared by every op.  Slot 1 carries the instance-norm partials
+    from a convolution epilogue to the norm that follows it."""
+    dev = (torch.cuda.current_device(), slot)
     buf = _ws_cache.get(dev)
     if buf is None or buf.numel() < nbytes:
         n = max(int(nbytes), 1 << 20)

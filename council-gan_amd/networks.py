@@ -44,9 +44,9 @@ class AdaptiveInstanceNorm2d(nn.Module):
         self.register_buffer('running_mean', torch.zeros(num_features))
         self.register_buffer('running_var', torch.ones(num_features))
 
-    def forward(self, x, act='none', residual=None):
+    def forward(self, x, act='none', residual=None, stats=None):
         assert self.params is not None, "Please assign weight and bias before calling AdaIN!"
-        return ops.adain(x, self.params, self.goff, self.boff, act=act, residual=residual, eps=self.eps)
+        return ops.adain(x, self.params, self.goff, self.boff, act=act, residual=residual, eps=self.eps, stats=stats)
 
     def __repr__(self):
         return self.__class__.__name__ + '(' + str(self.num_features) + ')'
@@ -107,12 +107,13 @@ class Conv2dBlock(nn.Module):
     def forward(self, x, x2=None, upsample=False, residual=None):
         act = self.activation_type
         fused_act = act if self.norm is None else 'none'
+        stats = [] if self.norm_type in ('in', 'adain') else None     # conv epilogue -> norm statistics hand-off
         y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, fused_act, x2=x2,
-                       upsample=upsample)
+                       upsample=upsample, stats=stats)
         if self.norm_type == 'in':
-            y = ops.instance_norm(y, act=act, residual=residual, eps=self.norm.eps)
+            y = ops.instance_norm(y, act=act, residual=residual, eps=self.norm.eps, stats=stats)
         elif self.norm_type == 'adain':
-            y = self.norm(y, act=act, residual=residual)
+            y = self.norm(y, act=act, residual=residual, stats=stats)
         elif self.norm_type == 'ln':
             y = ops.activation(self.norm(y), act)
             if residual is not None:

@@ -103,7 +103,7 @@ class _Conv2d(torch.autograd.Function):
     """act(conv2d(zero_pad(x (++ x2)), weight) + bias); networks.py:515-521 without the norm."""
 
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, wgrad_buf, bgrad_buf, stride, pad, act, up):
+    def forward(ctx, x, x2, weight, bias, wgrad_buf, bgrad_buf, stride, pad, act, up, stats):
         lib = _lib()
         x, x2, w = nhwc(x), nhwc(x2), nhwc(weight)
         N, C1, H, W = x.shape
@@ -115,7 +115,17 @@ class _Conv2d(torch.autograd.Function):
             raise ValueError("concat sources must agree in N, H, W")
         g = fwd_geom(N, H, W, C1, C2, int(up), KH, KW, stride, pad, Cout, act)
         y = empty_nhwc(N, Cout, g.Ho, g.Wo, x)
-        check(lib.cg_conv2d_fwd(byref(g), ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), stream()), "cg_conv2d_fwd")
+        if stats is not None and act == 0:
+            # an instance norm follows: let the conv epilogue emit its partial sums (ops.instance_norm consumes them)
+            m = N * g.Ho * g.Wo
+            sws = workspace(((m + 63) // 64) * Cout * 16, slot=1)
+            rows = ctypes.c_int(0)
+            check(lib.cg_conv2d_fwd_stats(byref(g), ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), ptr(sws), sws.numel(),
+                                          byref(rows), stream()), "cg_conv2d_fwd_stats")
+            if rows.value:
+                stats.append((sws, rows.value))
+        else:
+            check(lib.cg_conv2d_fwd(byref(g), ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), stream()), "cg_conv2d_fwd")
         ctx.save_for_backward(x, x2, w, y if act else None)
         ctx.g, ctx.meta = g, (KH, KW, stride, pad, act, int(up), bias is not None)
         ctx.wgrad_buf, ctx.bgrad_buf = wgrad_buf, bgrad_buf
@@ -154,14 +164,16 @@ class _Conv2d(torch.autograd.Function):
         dx2 = None
         if x2 is not None and ctx.needs_input_grad[1]:
             dx2 = conv_dgrad(g, dz, w, x.shape[1], x2.shape[1])
-        return dx, dx2, dw, db, None, None, None, None, None, None
+        return dx, dx2, dw, db, None, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=False):
-    """Functional conv.  `weight` may be an nn.Parameter managed by a flat optimizer buffer."""
+def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=False, stats=None):
+    """Functional conv.  `weight` may be an nn.Parameter managed by a flat optimizer buffer.  `stats`: an empty
+    list when an instance norm consumes the output next -- the conv appends (partials, rows) if its epilogue
+    produced the norm's partial sums (pass the same list to instance_norm / adain)."""
     return _Conv2d.apply(x, x2, weight, bias, getattr(weight, "_cg_grad", None),
                          getattr(bias, "_cg_grad", None) if bias is not None else None,
-                         int(stride), int(pad), ACT[act], bool(upsample))
+                         int(stride), int(pad), ACT[act], bool(upsample), stats)
 
 
 def linear(x, weight, bias=None, act="none"):
@@ -169,7 +181,7 @@ def linear(x, weight, bias=None, act="none"):
     n = x.shape[0]
     w4 = weight.view(weight.shape[0], weight.shape[1], 1, 1)
     y = _Conv2d.apply(x.reshape(n, -1, 1, 1), None, w4, bias, getattr(weight, "_cg_grad", None),
-                      getattr(bias, "_cg_grad", None) if bias is not None else None, 1, 0, ACT[act], False)
+                      getattr(bias, "_cg_grad", None) if bias is not None else None, 1, 0, ACT[act], False, None)
     return y.reshape(n, -1)
 
 
@@ -181,16 +193,21 @@ class _InstNormAct(torch.autograd.Function):
     of `params` ([N, P], the MLP output, networks.py:303-312) or absent (plain nn.InstanceNorm2d)."""
 
     @staticmethod
-    def forward(ctx, x, params, goff, boff, residual, act, eps):
+    def forward(ctx, x, params, goff, boff, residual, act, eps, stats):
         lib = _lib()
         x, residual = nhwc(x), nhwc(residual)
         N, C, H, W = x.shape
         HW = H * W
         mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        ws = workspace(lib.cg_instnorm_workspace(N, HW, C))
-        check(lib.cg_instnorm_stats(ptr(x), N, HW, C, eps, ptr(mean), ptr(rstd), ptr(ws), ws.numel(), stream()),
-              "cg_instnorm_stats")
+        if stats:
+            part, rows = stats[0]
+            check(lib.cg_instnorm_stats_from_partials(ptr(part), N, HW, C, rows, eps, ptr(mean), ptr(rstd), stream()),
+                  "cg_instnorm_stats_from_partials")
+        else:
+            ws = workspace(lib.cg_instnorm_workspace(N, HW, C))
+            check(lib.cg_instnorm_stats(ptr(x), N, HW, C, eps, ptr(mean), ptr(rstd), ptr(ws), ws.numel(), stream()),
+                  "cg_instnorm_stats")
         y = torch.empty_like(x)
         if params is not None:
             params = params.contiguous()
@@ -229,15 +246,15 @@ class _InstNormAct(torch.autograd.Function):
             gs = C
         check(lib.cg_instnorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(dx), dgp, dbp, N, HW, C, act,
                                   ptr(ws), ws.numel(), stream()), "cg_instnorm_bwd")
-        return dx, dparams, None, None, (dy if has_res else None), None, None
+        return dx, dparams, None, None, (dy if has_res else None), None, None, None
 
 
-def instance_norm(x, act="none", residual=None, eps=1e-5):
-    return _InstNormAct.apply(x, None, 0, 0, residual, ACT[act], float(eps))
+def instance_norm(x, act="none", residual=None, eps=1e-5, stats=None):
+    return _InstNormAct.apply(x, None, 0, 0, residual, ACT[act], float(eps), stats)
 
 
-def adain(x, params, goff, boff, act="none", residual=None, eps=1e-5):
-    return _InstNormAct.apply(x, params, int(goff), int(boff), residual, ACT[act], float(eps))
+def adain(x, params, goff, boff, act="none", residual=None, eps=1e-5, stats=None):
+    return _InstNormAct.apply(x, params, int(goff), int(boff), residual, ACT[act], float(eps), stats)
 
 
 class _Activation(torch.autograd.Function):

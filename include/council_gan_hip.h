@@ -71,6 +71,13 @@ int cg_version(void);
 int cg_conv2d_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
                   const float* bias, float* y, cg_stream_t stream);
 
+/* Forward conv that ALSO emits instance-norm partial statistics of y from its epilogue when the fused path applies
+ * (pipelined kernel, act == none, H*W a multiple of the block's row tile): stats[((n*S + s)*Cout + c)*2 + {0,1}] =
+ * {sum y, sum y^2} over rows [s*R, (s+1)*R) of sample n, R returned in *rows_per_partial (0 = not fused: run
+ * cg_instnorm_stats).  stats_bytes >= ceil(M/64)*Cout*16 always suffices.  Conv2dBlock conv -> norm, networks.py:515-518. */
+int cg_conv2d_fwd_stats(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
+                        float* y, double* stats, size_t stats_bytes, int* rows_per_partial, cg_stream_t stream);
+
 /* Same, with the block-tile configuration forced (tuning / A-B benchmarking hook; -1 = heuristic). */
 int cg_conv2d_fwd_tile(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
                        const float* bias, float* y, int tile_cfg, cg_stream_t stream);
@@ -111,6 +118,9 @@ int cg_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, cg
 size_t cg_instnorm_workspace(int N, int HW, int C);
 int cg_instnorm_stats(const float* x, int N, int HW, int C, float eps, float* mean, float* rstd, void* ws,
                       size_t ws_bytes, cg_stream_t stream);
+/* mean / rstd from the partials of cg_conv2d_fwd_stats */
+int cg_instnorm_stats_from_partials(const double* part, int N, int HW, int C, int rows_per_partial, float eps,
+                                    float* mean, float* rstd, cg_stream_t stream);
 /* y = act((x-mean)*rstd*gamma + beta) + residual; gamma/beta NULL = plain IN, else sample n /
  * channel c reads gamma[n*gstride + c] (gstride = C for a dense [N*C] vector; = row length when
  * gamma/beta point into the MLP output [N][P], networks.py:303-312); residual or NULL */
