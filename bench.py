@@ -161,7 +161,10 @@ def main():
 
     if rank == 0 and world == 1:
         step_tflops = wmin / (ms_per_step / 1000.0)
-        roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+        # traffic: HBM bytes per launch of the dominant kernel on its dominant shape (3x3 256->256 @64x64, 70 % of its
+        # launches) from rocprofv3 PMC passes -- 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, profiles/r01_conv_pmc_probe.txt;
+        # the algorithmic bytes of that shape are 36.0e6 (activations 16.8 + weights 2.4 + output 16.8 MB)
+        roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "traffic": 53.3e6,
                 "step_achieved": round(step_tflops, 2), "step_frac": round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4)}
         if not args.no_kernel_profile:
             # one more iteration with HIP events around every MFMA conv launch (on the launch stream)

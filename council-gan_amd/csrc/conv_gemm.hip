@@ -1170,7 +1170,7 @@ int launch_pipe_batch(PipeBatch& b, int ncls, const float* x1, const float* bias
     return CG_OK;
 }
 
-int pipe_cfg_bm(int cfg) { return cfg == 23 || cfg == 26 ? 64 : (cfg == 24 ? 256 : 128); }
+int pipe_cfg_bm(int cfg) { return cfg == 23 || cfg == 26 ? 64 : (cfg == 24 || cfg == 32 ? 256 : 128); }
 
 int launch_pipe_cfg(int cfg, PipeBatch& b, int ncls, const float* x1, const float* bias, float* y, unsigned x_bytes,
                     hipStream_t st, double* stats = nullptr) {
@@ -1187,6 +1187,7 @@ int launch_pipe_cfg(int cfg, PipeBatch& b, int ncls, const float* x1, const floa
         case 29: return launch_pipe_batch<128, 128, 64, 32, 1, 2>(b, ncls, x1, bias, y, x_bytes, st);  // ablation
         case 30: return launch_pipe_batch<128, 128, 64, 64, 2>(b, ncls, x1, bias, y, x_bytes, st);     // 4 waves, prefetch 2
         case 31: return launch_pipe_batch<128, 128, 64, 32, 1, 3>(b, ncls, x1, bias, y, x_bytes, st);  // timing probe
+        case 32: return launch_pipe_batch<256, 64, 64, 32>(b, ncls, x1, bias, y, x_bytes, st, stats);  // 8 waves
         default: return cg_set_error(CG_ERR_ARG, "pipelined conv: unknown tile configuration %d", cfg);
     }
 }
@@ -1229,7 +1230,8 @@ int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float*
         case 16: return launch_fwd<64, 128, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
         case 17: return launch_fwd<128, 128, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 16 waves
         case 18: return launch_fwd<256, 128, 64, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 16 waves
-        case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: {
+        case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31:
+        case 32: {
             if (!pipe_ok(g, K)) return cg_set_error(CG_ERR_ARG, "conv forward: configuration %d needs the pipelined path", cfg);
             PipeBatch b;
             fill_class(b.c[0], g, w);
@@ -1251,8 +1253,10 @@ int pick_fwd_cfg(const cg_conv_geom* g, int M, bool pipe) {
         return blocks128 < 96 ? 10 : 3;
     }
     if (g->Cout > 32) {
-        if ((M + 127) / 128 < 192) return pipe ? 23 : 3;
-        return pipe ? 22 : 1;
+        // 64 output channels: 8 waves of 32x32 on a 128x64 tile beat 4 waves of 64x32 by 4-6 % (two waves per SIMD);
+        // short-K (1x1) layers are bandwidth-bound and prefer the smaller tile (profiles/r01_conv_tiles_pipe.txt)
+        if ((M + 127) / 128 < 192 || g->T * (g->C1 + g->C2) <= 128) return pipe ? 23 : 3;
+        return pipe ? 25 : 1;
     }
     return 2;
 }
@@ -1291,10 +1295,11 @@ WgradPlan plan_wgrad(const cg_conv_geom* g) {
     const int slices = (M + 31) / 32;
     const int tiles = p.tiles_m * p.tiles_n;
     int want = (2 * 256) / tiles;                      // two co-resident blocks per CU, and no partial second round
+    if (K <= 128 && g->Cout <= 128) want *= 4;         // 1x1-class gradients are bandwidth-bound: more loads in flight
     int max_by_work = slices / 8 > 0 ? slices / 8 : 1; // >= 8 slices (256 positions) per split
     int s = want < max_by_work ? want : max_by_work;
     if (s < 1) s = 1;
-    if (s > 512) s = 512;
+    if (s > 2048) s = 2048;
     p.slices_per_split = (slices + s - 1) / s;
     p.splits = (slices + p.slices_per_split - 1) / p.slices_per_split;
     return p;

@@ -16,7 +16,7 @@ CFG_NAMES = {0: "128x128/4w/1s", 1: "128x64/4w/1s", 2: "128x32/4w/1s", 3: "64x64
              15: "256x64/8w/1s", 16: "64x128/8w/1s", 17: "128x128/16w", 18: "256x128/16w",
              20: "P128x128/8w", 21: "P128x128/4w", 22: "P128x64/4w", 23: "P64x64/4w", 24: "P256x128/8w",
              25: "P128x64/8w", 26: "P64x128/4w", 27: "P128x128/8w/pf2", 28: "abl:fixedslice", 29: "abl:nostagger",
-             30: "P128x128/4w/pf2"}
+             30: "P128x128/4w/pf2", 32: "P256x64/8w"}
 SKIP = {1, 2, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18}      # double-buffered / 256x128-8w variants: measured, never better (profiles/r01_conv_tiles.txt)
 
 SHAPES = [
@@ -35,6 +35,9 @@ SHAPES = [
     ("DC 256->512 4x4s2 @64 b16", 16, 64, 64, 256, 512, 4, 2, 1, 0),
     ("1x1 64->64 @256", 4, 256, 256, 64, 64, 1, 1, 0, 0),
     ("dgrad-class 256x4taps->128 @64", 4, 64, 64, 256, 128, 2, 1, 0, 0),
+    ("DCdgrad-class 128x4taps->64 @128 b16", 16, 128, 128, 128, 64, 2, 1, 0, 0),
+    ("D 512->512 1x1 @32 b16", 16, 32, 32, 512, 512, 1, 1, 0, 0),
+    ("Ddgrad-class 512x4taps->256 @16 b4", 4, 16, 16, 512, 256, 2, 1, 0, 0),
 ]
 
 
