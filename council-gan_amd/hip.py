@@ -133,7 +133,7 @@ def workspace(nbytes, slot=0):
     """Per-device scratch owned by PyTorch's caching allocator; kernels on one stream are ordered,
     so one buffer per device (and slot) is shared by every op.  Slot 1 carries the instance-norm partials
     from a convolution epilogue to the norm that follows it."""
-    dev = (torch.cuda.current_device(), slot)
+    dev = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, slot)   # one scratch per stream
     buf = _ws_cache.get(dev)
     if buf is None or buf.numel() < nbytes:
         n = max(int(nbytes), 1 << 20)

@@ -21,6 +21,7 @@ m // members_per_rank); everything host-side (batch, style noise, Python RNG pic
 the ONLY collective on the data path is one all-gather of the generated images in
 `dis_council_update` (the cross-member dependency at trainer_council.py:853-856, 872-874).
 """
+import contextlib
 import os
 import random
 import warnings
@@ -180,6 +181,7 @@ class Council_Trainer(nn.Module):
         # encode the SAME batch with the SAME generator weights, so the encoder runs once per iteration
         self._img_cache = {}
         self._enc_cache = {}
+        self._streams = []
 
     # ------------------------------------------------------------------------------------
     # device placement
@@ -208,7 +210,29 @@ class Council_Trainer(nn.Module):
                                torch.ones(1, device=dev))
                            for i in self.shard.local} for d in self._dirs}
         self._device = dev
+        # Council members are independent models: each local member's kernels go to its own HIP stream, so the
+        # low-occupancy launches of one member (16x16 / 8x8 discriminator layers, 1-block-per-CU convs) overlap with
+        # another member's work.  CG_MEMBER_STREAMS=1 serialises everything on the caller's stream.
+        n = min(int(os.environ.get('CG_MEMBER_STREAMS', '2')), len(self.shard.local))
+        self._streams = [torch.cuda.Stream(device=dev) for _ in range(n)] if n > 1 else []
         return self
+
+    def _fork(self):
+        """Member streams start after everything already queued on the caller's stream."""
+        cur = torch.cuda.current_stream()
+        for st in self._streams:
+            st.wait_stream(cur)
+
+    def _join(self):
+        """The caller's stream continues after every member stream."""
+        cur = torch.cuda.current_stream()
+        for st in self._streams:
+            cur.wait_stream(st)
+
+    def _on(self, i):
+        if not self._streams:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(self._streams[self.shard.local.index(i) % len(self._streams)])
 
     def to(self, *args, **kwargs):
         dev = args[0] if args else kwargs.get('device')
@@ -282,22 +306,25 @@ class Council_Trainer(nn.Module):
             s['b2a'] = self._noise(x_a.size(0)).to(self._device)
             self.loss_dis_b2a_s = [0] * self.council_size
         self.loss_dis_total_s = [0] * self.council_size
+        self._fork()
         for i in self.shard.local:
-            total = None
-            for d in self._dirs:
-                gen = self._nets('gen', d)[i]
-                content = self._content(d, i, x[d], need_grad=False)
-                with torch.no_grad():
-                    x_fake = gen.decode(content, s[d], x[d])
-                # :775-777 -- only the a2b term is scaled by gan_w (reference quirk, kept); the scale is
-                # folded into the per-sample loss weights
-                w = float(hp['gan_w']) if d == 'a2b' else 1.0
-                l = self._nets('dis', d)[i].calc_dis_loss(x_fake, tgt[d], weight=w)
-                getattr(self, 'loss_dis_%s_s' % d)[i] = l.detach() / w if w != 1.0 else l.detach()
-                total = l if total is None else total + l
-            self.loss_dis_total_s[i] = total.detach()
-            total.backward()
-            self.dis_opt_s[i].step()
+            with self._on(i):
+                total = None
+                for d in self._dirs:
+                    gen = self._nets('gen', d)[i]
+                    content = self._content(d, i, x[d], need_grad=False)
+                    with torch.no_grad():
+                        x_fake = gen.decode(content, s[d], x[d])
+                    # :775-777 -- only the a2b term is scaled by gan_w (reference quirk, kept); the scale is
+                    # folded into the per-sample loss weights
+                    w = float(hp['gan_w']) if d == 'a2b' else 1.0
+                    l = self._nets('dis', d)[i].calc_dis_loss(x_fake, tgt[d], weight=w)
+                    getattr(self, 'loss_dis_%s_s' % d)[i] = l.detach() / w if w != 1.0 else l.detach()
+                    total = l if total is None else total + l
+                self.loss_dis_total_s[i] = total.detach()
+                total.backward()
+                self.dis_opt_s[i].step()
+        self._join()
 
     # ------------------------------------------------------------------------------------
     # dis_council_update, trainer_council.py:782-883
@@ -331,13 +358,16 @@ class Council_Trainer(nn.Module):
 
         x_full = {d: {} for d in self._dirs}
         x_cmp_local = {d: [] for d in self._dirs}
+        self._fork()
         for i in self.shard.local:
-            for d in self._dirs:
-                gen = self._nets('gen', d)[i]
-                content = self._content(d, i, x[d], need_grad=False)
-                with torch.no_grad():
-                    x_full[d][i] = gen.decode(content, s[d], x[d])
-                    x_cmp_local[d].append(gen.decode(content, s_less[d], x[d]) if less != 0 else x_full[d][i])
+            with self._on(i):
+                for d in self._dirs:
+                    gen = self._nets('gen', d)[i]
+                    content = self._content(d, i, x[d], need_grad=False)
+                    with torch.no_grad():
+                        x_full[d][i] = gen.decode(content, s[d], x[d])
+                        x_cmp_local[d].append(gen.decode(content, s_less[d], x[d]) if less != 0 else x_full[d][i])
+        self._join()      # every member's council discriminator reads the OTHER members' images
         # the ONE cross-member exchange (trainer_council.py:853-856): every member's comparison image
         x_cmp = {d: self.shard.exchange(x_cmp_local[d]) for d in self._dirs}
 
@@ -345,21 +375,25 @@ class Council_Trainer(nn.Module):
         self.loss_dis_council_b2a_s = [0] * self.council_size
         self.loss_dis_council_total_s = [0] * self.council_size
         scale = float(hp['council_w']) / float(n_rel)                      # :878-880
+        self._fork()
         for i in range(self.council_size):
             picks = self.draw_colleagues(i, self.council_size, n_rel)     # every rank replays every member's draws
             if i not in self.shard.local:
                 continue
             uniq = sorted(set(picks))
             mult = [float(picks.count(j)) for j in uniq]
-            total = None
-            for d in self._dirs:
-                l = self._nets('disc', d)[i].calc_dis_loss_multi(
-                    x_full[d][i], [x_cmp[d][j] for j in uniq], mult, x[d], fake_weight=float(len(picks)), weight=scale)
-                getattr(self, 'loss_dis_council_%s_s' % d)[i] = l.detach() / scale
-                total = l if total is None else total + l
-            self.loss_dis_council_total_s[i] = total.detach()
-            total.backward()
-            self.dis_council_opt_s[i].step()
+            with self._on(i):
+                total = None
+                for d in self._dirs:
+                    l = self._nets('disc', d)[i].calc_dis_loss_multi(
+                        x_full[d][i], [x_cmp[d][j] for j in uniq], mult, x[d], fake_weight=float(len(picks)),
+                        weight=scale)
+                    getattr(self, 'loss_dis_council_%s_s' % d)[i] = l.detach() / scale
+                    total = l if total is None else total + l
+                self.loss_dis_council_total_s[i] = total.detach()
+                total.backward()
+                self.dis_council_opt_s[i].step()
+        self._join()
 
     @staticmethod
     def draw_colleagues(i, council_size, n_rel):
@@ -426,52 +460,55 @@ class Council_Trainer(nn.Module):
                         if p.requires_grad:
                             p.requires_grad_(False)
                             frozen.append(p)
+        self._fork()
         try:
             for i in self.shard.local:
-                total = None
-                for d in self._dirs:
-                    gen = self._nets('gen', d)[i]
-                    x_fake = gen.decode(self._content(d, i, x[d], need_grad=True), s[d], x[d])
-                    mask = gen.dec.mask_s
-                    terms = []
-                    if focus_on:                                                   # :390-451
-                        ftot, parts = ops.focus_loss(mask, fl['mask_zero_or_one_center'], fl['mask_zero_or_one_epsilon'],
-                                                     hp['mask_zero_or_one_w'], hp['mask_total_w'], hp['mask_tv_w'],
-                                                     fl['mask_small_use_abs'], fl['mask_small_use_square'])
-                        terms.append(ftot)
-                        if hp['mask_zero_or_one_w'] != 0:
-                            getattr(self, 'loss_gen_mask_zero_one_%s_s' % ab[d])[i] = parts[0]
-                        if hp['mask_total_w'] != 0:
-                            getattr(self, 'loss_gen_mask_total_%s_s' % ab[d])[i] = parts[1]
-                        if hp['mask_tv_w'] != 0:
-                            getattr(self, 'loss_gen_mask_TV_%s_s' % ab[d])[i] = parts[2]
-                    if hp['gan_w'] != 0:                                           # :498-529
-                        adv = self._nets('dis', d)[i].calc_gen_loss(x_fake)
-                        getattr(self, 'loss_gen_adv_%s_s' % d)[i] = adv.detach()
-                        ring_g, ring_c, w_dev = self._rings[d][i]
-                        if self.do_w_loss_matching:
-                            check(lib.cg_ring_push(ptr(ring_g), self._ring_n, self._ring_pos[d][i], ptr(adv.detach()),
-                                                   stream()), "cg_ring_push")
-                            self._ring_pos[d][i] += 1
-                        terms.append(adv * float(hp['gan_w']))
-                    if council_on:                                                 # :558-624
-                        lc = self._nets('disc', d)[i].calc_gen_loss(x_fake, x[d])
-                        if self.do_w_loss_matching:
+                with self._on(i):
+                    total = None
+                    for d in self._dirs:
+                        gen = self._nets('gen', d)[i]
+                        x_fake = gen.decode(self._content(d, i, x[d], need_grad=True), s[d], x[d])
+                        mask = gen.dec.mask_s
+                        terms = []
+                        if focus_on:                                                   # :390-451
+                            ftot, parts = ops.focus_loss(mask, fl['mask_zero_or_one_center'], fl['mask_zero_or_one_epsilon'],
+                                                         hp['mask_zero_or_one_w'], hp['mask_total_w'], hp['mask_tv_w'],
+                                                         fl['mask_small_use_abs'], fl['mask_small_use_square'])
+                            terms.append(ftot)
+                            if hp['mask_zero_or_one_w'] != 0:
+                                getattr(self, 'loss_gen_mask_zero_one_%s_s' % ab[d])[i] = parts[0]
+                            if hp['mask_total_w'] != 0:
+                                getattr(self, 'loss_gen_mask_total_%s_s' % ab[d])[i] = parts[1]
+                            if hp['mask_tv_w'] != 0:
+                                getattr(self, 'loss_gen_mask_TV_%s_s' % ab[d])[i] = parts[2]
+                        if hp['gan_w'] != 0:                                           # :498-529
+                            adv = self._nets('dis', d)[i].calc_gen_loss(x_fake)
+                            getattr(self, 'loss_gen_adv_%s_s' % d)[i] = adv.detach()
                             ring_g, ring_c, w_dev = self._rings[d][i]
-                            check(lib.cg_loss_match(ptr(ring_g), ptr(ring_c), self._ring_n, self._ring_pos_c[d][i],
-                                                    ptr(lc.detach()), ptr(w_dev), stream()), "cg_loss_match")
-                            self._ring_pos_c[d][i] += 1
-                            setattr(self, 'w_match_%s_conf' % d, w_dev[0])
-                            lc = lc * w_dev[0]
-                        lc = lc * float(hp['council_w'])
-                        getattr(self, 'council_loss_%s_s' % ab[d])[i] = lc.detach()
-                        terms.append(lc)
-                    for t in terms:
-                        total = t if total is None else total + t
-                self.loss_gen_total_s[i] = total.detach()
-                total.backward()
-                self.gen_opt_s[i].step()
+                            if self.do_w_loss_matching:
+                                check(lib.cg_ring_push(ptr(ring_g), self._ring_n, self._ring_pos[d][i], ptr(adv.detach()),
+                                                       stream()), "cg_ring_push")
+                                self._ring_pos[d][i] += 1
+                            terms.append(adv * float(hp['gan_w']))
+                        if council_on:                                                 # :558-624
+                            lc = self._nets('disc', d)[i].calc_gen_loss(x_fake, x[d])
+                            if self.do_w_loss_matching:
+                                ring_g, ring_c, w_dev = self._rings[d][i]
+                                check(lib.cg_loss_match(ptr(ring_g), ptr(ring_c), self._ring_n, self._ring_pos_c[d][i],
+                                                        ptr(lc.detach()), ptr(w_dev), stream()), "cg_loss_match")
+                                self._ring_pos_c[d][i] += 1
+                                setattr(self, 'w_match_%s_conf' % d, w_dev[0])
+                                lc = lc * w_dev[0]
+                            lc = lc * float(hp['council_w'])
+                            getattr(self, 'council_loss_%s_s' % ab[d])[i] = lc.detach()
+                            terms.append(lc)
+                        for t in terms:
+                            total = t if total is None else total + t
+                    self.loss_gen_total_s[i] = total.detach()
+                    total.backward()
+                    self.gen_opt_s[i].step()
         finally:
+            self._join()
             for p in frozen:
                 p.requires_grad_(True)
 
