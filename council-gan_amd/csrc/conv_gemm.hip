@@ -1104,8 +1104,8 @@ struct ProfScope {
                      bn, g->N, g->H, g->W, g->C1 + g->C2, g->Cout, g->T, g->stride, g->up, g->Ho, g->Wo, ncls);
         rec.slot = family * 16 + tile_id(bm, bn) * 2 + (fast ? 1 : 0);
         rec.flops = flops;
-        static const char* const fam[4] = {"conv_fwd_kernel", "conv_wgrad_kernel", "conv_fwd_pipe_kernel",
-                                           "conv_wgrad_pipe_kernel"};
+        static const char* const fam[5] = {"conv_fwd_kernel", "conv_wgrad_kernel", "conv_fwd_pipe_kernel",
+                                           "conv_wgrad_pipe_kernel", "conv_fwd_x3_kernel"};
         snprintf(prof_names[rec.slot], sizeof(prof_names[0]), "%s<%d,%d,%s>", fam[family], bm, bn, fast ? "fast" : "generic");
         (void)hipEventCreate(&rec.e0);
         (void)hipEventCreate(&rec.e1);
@@ -1200,6 +1200,8 @@ void fill_class(PipeClass& pc, const cg_conv_geom* g, const float* w) {
     pc.w_bytes = (unsigned)((size_t)g->Cout * pc.K * sizeof(float));
     pc.pad_ = 0;
 }
+
+#include "conv_x3.inc"
 
 // the pipelined kernel needs: one source, channels a multiple of BK, operands addressable with 31-bit byte offsets
 bool pipe_ok(const cg_conv_geom* g, int K) {
@@ -1393,6 +1395,63 @@ extern "C" int cg_conv2d_fwd_stats(const cg_conv_geom* g, const float* x1, const
         }
     }
     return launch_fwd_cfg(cfg, g, x1, x2, w, bias, y, M, K, fast, cg_s(stream), st_ptr);
+}
+
+// ---- split-precision forward (conv_x3.inc) --------------------------------------------------------
+extern "C" int cg_split_f16(const float* x, void* out, size_t n, size_t lo_elems, float scale, cg_stream_t stream) {
+    CG_CHECK_ARG(x && out && n > 0 && lo_elems >= n && scale > 0.f, "cg_split_f16: bad args");
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, cg_s(stream), x, (_Float16*)out, n, lo_elems,
+                       scale);
+    CG_LAUNCH_CHECK("split_f16_kernel");
+    return CG_OK;
+}
+
+extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_lo_elems, const void* ws,
+                                size_t w_lo_elems, float w_scale, const float* bias, float* y, double* stats,
+                                size_t stats_bytes, int* rows_per_partial, int tile_cfg, cg_stream_t stream) {
+    int rc = validate_geom(g, "cg_conv2d_fwd_x3");
+    if (rc) return rc;
+    CG_CHECK_ARG(xs && ws && y && w_scale > 0.f, "cg_conv2d_fwd_x3: null pointer / bad scale");
+    const int K = g->T * g->C1;
+    const int M = g->N * g->Ho * g->Wo;
+    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, w_plane = (size_t)g->Cout * K * 2;
+    CG_CHECK_ARG(x_lo_elems * 2 >= x_plane && w_lo_elems * 2 >= w_plane, "cg_conv2d_fwd_x3: lo plane overlaps the hi plane");
+    const size_t x_span = x_lo_elems * 2 + x_plane, w_span = w_lo_elems * 2 + w_plane;
+    CG_CHECK_ARG(g->C2 == 0 && g->C1 % BK == 0 && x_span < (size_t)CG_OOB && w_span < (size_t)CG_OOB,
+                 "cg_conv2d_fwd_x3: needs one source with C %% 32 == 0 and operands spanning < 2 GiB");
+    PipeBatch b;
+    fill_class(b.c[0], g, (const float*)ws);
+    b.c[0].w_bytes = (unsigned)(w_lo_elems * 2);
+    b.c[0].pad_ = (int32_t)w_span;
+    int cfg = tile_cfg;
+    if (cfg < 0) {
+        // measured (profiles/r01_x3.txt): 8 waves of 64x32 on 128x128 for wide layers, 8 waves of 32x32 on 128x64
+        // for 64 output channels, 64x64 when the problem has few tiles
+        const long blocks128 = (long)((M + 127) / 128) * ((g->Cout + 127) / 128);
+        cfg = g->Cout > 64 ? (blocks128 >= 192 ? 1 : 3) : (g->Cout > 32 && (M + 127) / 128 >= 192 ? 2 : 3);
+    }
+    const int bm = cfg == 3 ? 64 : 128;
+    double* st_ptr = nullptr;
+    if (rows_per_partial) {
+        *rows_per_partial = 0;
+        if (stats && g->act == CG_ACT_NONE && g->osy == 1 && g->osx == 1 && (g->Ho * g->Wo) % bm == 0 &&
+            stats_bytes >= (size_t)(M / bm) * g->Cout * 2 * sizeof(double)) {
+            st_ptr = stats;
+            *rows_per_partial = bm;
+        }
+    }
+    hipStream_t st = cg_s(stream);
+    const unsigned xl = (unsigned)(x_lo_elems * 2), xsp = (unsigned)x_span;
+    switch (cfg) {
+        case 0: return launch_x3<128, 128, 64, 64>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr);   // 4 waves
+        case 1: return launch_x3<128, 128, 64, 32>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr);   // 8 waves
+        case 2: return launch_x3<128, 64, 32, 32>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr);    // 8 waves
+        case 3: return launch_x3<64, 64, 32, 32>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr);     // 4 waves
+        default: return cg_set_error(CG_ERR_ARG, "cg_conv2d_fwd_x3: unknown tile configuration %d", cfg);
+    }
 }
 
 extern "C" int cg_conv2d_fwd_tile(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,

@@ -268,6 +268,43 @@ __global__ __launch_bounds__(256) void in_apply_q(const float* __restrict__ x, c
     }
 }
 
+// same, writing the {hi, lo} fp16 planes the split-precision convolution consumes (and optionally fp32 as well)
+template <bool RES, bool F32>
+__global__ __launch_bounds__(256) void in_apply_split_q(const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ residual,
+                                                        float* __restrict__ y, _Float16* __restrict__ ys, size_t lo_elems,
+                                                        int HW, int C, int act, int gs) {
+    const int n = blockIdx.y;
+    const int nq = HW * (C >> 2);
+    const int step = gridDim.x * 256;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    const int c = (i % (C >> 2)) << 2;
+    const Quad q = load_quad(mean, rstd, gamma, beta, n, C, c, gs);
+    const size_t base = (size_t)n * HW * C;
+    x += base; ys += base;
+    if (F32) y += base;
+    if (RES) residual += base;
+    for (; i < nq; i += step) {
+        const float4 v = ld4(x + 4 * (size_t)i);
+        float4 rr;
+        if (RES) rr = ld4(residual + 4 * (size_t)i);
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = cg_apply_act((o[k] - q.m[k]) * q.r[k] * q.g[k] + q.b[k], act);
+        if (RES) { o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w; }
+        if (F32) st4(y + 4 * (size_t)i, make_float4(o[0], o[1], o[2], o[3]));
+        _Float16 h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = (_Float16)fminf(fmaxf(o[k], -65504.f), 65504.f);
+            l[k] = (_Float16)(o[k] - (float)h[k]);
+        }
+        *reinterpret_cast<uint2*>(ys + 4 * (size_t)i) = *reinterpret_cast<const uint2*>(h);
+        *reinterpret_cast<uint2*>(ys + lo_elems + 4 * (size_t)i) = *reinterpret_cast<const uint2*>(l);
+    }
+}
+
 // the reference applies gamma as a multiplier of the normalised value: keep (x-m)*r first, then *g (same rounding
 // order as in_apply_kernel)
 
@@ -558,6 +595,25 @@ extern "C" int cg_instnorm_apply(const float* x, const float* mean, const float*
         hipLaunchKernelGGL((in_apply_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, cg_s(stream), x, mean, rstd,
                            gamma, beta, residual, y, total, HW, C, act, gstride);
     CG_LAUNCH_CHECK("in_apply_kernel");
+    return CG_OK;
+}
+
+extern "C" int cg_instnorm_apply_split(const float* x, const float* mean, const float* rstd, const float* gamma,
+                                       const float* beta, int gstride, const float* residual, float* y, void* y_split,
+                                       size_t y_lo_elems, int N, int HW, int C, int act, cg_stream_t stream) {
+    CG_CHECK_ARG(x && mean && rstd && y_split && N > 0 && HW > 0 && C > 0, "cg_instnorm_apply_split: bad args");
+    CG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "cg_instnorm_apply_split: gamma and beta go together");
+    CG_CHECK_ARG(quad_ok(C) && (size_t)HW * C < (size_t)0x7fffffff && y_lo_elems >= (size_t)N * HW * C,
+                 "cg_instnorm_apply_split: channel count %d / plane offset not supported", C);
+    dim3 grid(quad_grid(HW, C, N), N);
+    _Float16* ys = (_Float16*)y_split;
+#define CG_AS(RES_, F32_)                                                                                                  \
+    hipLaunchKernelGGL((in_apply_split_q<RES_, F32_>), grid, dim3(256), 0, cg_s(stream), x, mean, rstd, gamma, beta, residual, \
+                       y, ys, y_lo_elems, HW, C, act, gstride)
+    if (residual) { if (y) CG_AS(true, true); else CG_AS(true, false); }
+    else { if (y) CG_AS(false, true); else CG_AS(false, false); }
+#undef CG_AS
+    CG_LAUNCH_CHECK("in_apply_split_q");
     return CG_OK;
 }
 

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcouncilgan_hip.so")
 
 ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "tanh": 3}
 MAX_TAPS = 64
+X3_WSCALE = 1024.0      # CG_X3_WSCALE: power-of-two pre-scale of split-precision weights
 
 
 class ConvGeom(ctypes.Structure):
@@ -36,6 +37,10 @@ _SIGS = {
     "cg_conv2d_fwd": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P]),
     "cg_conv2d_fwd_stats": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_size_t, POINTER(c_int), _P]),
     "cg_instnorm_stats_from_partials": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
+    "cg_split_f16": (c_int, [_P, _P, c_size_t, c_size_t, c_float, _P]),
+    "cg_conv2d_fwd_x3": (c_int, [POINTER(ConvGeom), _P, c_size_t, _P, c_size_t, c_float, _P, _P, _P, c_size_t, POINTER(c_int),
+                                 c_int, _P]),
+    "cg_instnorm_apply_split": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, _P]),
     "cg_conv2d_fwd_tile": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P]),
     "cg_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvGeom)]),
     "cg_conv2d_wgrad": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
@@ -121,7 +126,7 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise HipError("tensor on %s passed to a HIP kernel: the hot path has no CPU fallback" % t.device)
-    if t.dtype != torch.float32 and t.dtype != torch.int32 and t.dtype != torch.uint8:
+    if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.float16):
         raise HipError("unsupported dtype %s" % t.dtype)
     return c_void_p(t.data_ptr())
 
@@ -143,7 +148,7 @@ def workspace(nbytes, slot=0):
     return buf
 
 
-PROF_SLOTS = 64
+PROF_SLOTS = 80
 
 
 def prof_enable(on):

@@ -123,6 +123,28 @@ class Conv2dBlock(nn.Module):
         return y
 
 
+def _split_ok(block):
+    """A Conv2dBlock the split-precision path can run: instance-norm / AdaIN after a conv whose input width is a
+    multiple of 32, with its weight registered in a split-weight table (Council_Trainer refreshes it)."""
+    return (getattr(block, '_cg_wsplit', None) is not None and block.norm_type in ('in', 'adain')
+            and block.conv.in_channels % 32 == 0 and block.conv.out_channels % 4 == 0)
+
+
+def conv_block_split(block, xs, upsample=False, residual=None, want_f32=False):
+    """Conv2dBlock.forward on split-precision operands (tape-free passes only): returns (y_fp32_or_None, SplitTensor)."""
+    k = block.kernel_size
+    stats = []
+    y = ops.conv2d_x3(xs, block._cg_wsplit, block.conv.out_channels, k, k, block.conv.bias, block.stride, block.padding,
+                       'none', upsample=upsample, stats=stats)
+    if block.norm_type == 'adain':
+        n = block.norm
+        assert n.params is not None, "Please assign weight and bias before calling AdaIN!"
+        return ops.instnorm_split(y, n.params, n.goff, n.boff, act=block.activation_type, residual=residual, eps=n.eps,
+                                  stats=stats, want_f32=want_f32)
+    return ops.instnorm_split(y, None, 0, 0, act=block.activation_type, residual=residual, eps=block.norm.eps,
+                              stats=stats, want_f32=want_f32)
+
+
 class ResBlock(nn.Module):
     """networks.py:448-461; `out += residual` is fused into the second norm's apply pass."""
 
@@ -245,6 +267,7 @@ class Decoder_V2_atten(nn.Module):
         self.output_dim = output_dim
         self.n_upsample = n_upsample
         self.mask_s = []
+        self.split_active = False
         model = [ResBlocks(n_res, dim, res_norm, activ, pad_type=pad_type)]
         for _ in range(n_upsample):
             model += [nn.Upsample(scale_factor=2)]      # placeholder: fused into the next conv's gather
@@ -257,13 +280,42 @@ class Decoder_V2_atten(nn.Module):
                               norm='none', activation='tanh', pad_type=pad_type)]
         self.model = nn.Sequential(*model)
 
-    def forward(self, x, im_in, return_mask=False):
-        y = self.model[0](x)
+    def _split_blocks(self):
+        blocks = []
+        for blk in self.model[0].model:
+            blocks += [blk.model[0], blk.model[1]]
         i = 1
         for _ in range(self.n_upsample):
-            y = self.model[i + 1](y, upsample=True)
-            y = self.model[i + 2](y)
+            blocks += [self.model[i + 1], self.model[i + 2]]
             i += 3
+        return blocks
+
+    def _trunk_split(self, x):
+        """ResBlocks + upsampling convs on the split-precision path (tape-free passes only):
+        every 3x3 conv reads {hi, lo} fp16 planes written by the AdaIN apply before it."""
+        xs = ops.split_f16(x)
+        for blk in self.model[0].model:
+            _, zs = conv_block_split(blk.model[0], xs)
+            x, xs = conv_block_split(blk.model[1], zs, residual=x, want_f32=True)
+        i = 1
+        for u in range(self.n_upsample):
+            _, zs = conv_block_split(self.model[i + 1], xs, upsample=True)
+            last = u + 1 == self.n_upsample
+            x, xs = conv_block_split(self.model[i + 2], zs, want_f32=last)
+            i += 3
+        return x, i
+
+    def forward(self, x, im_in, return_mask=False):
+        # split-precision trunk: only inside Council_Trainer's tape-free passes, which keep the split weights current
+        if self.split_active and not torch.is_grad_enabled() and all(_split_ok(b) for b in self._split_blocks()):
+            y, i = self._trunk_split(x)
+        else:
+            y = self.model[0](x)
+            i = 1
+            for _ in range(self.n_upsample):
+                y = self.model[i + 1](y, upsample=True)
+                y = self.model[i + 2](y)
+                i += 3
         y = self.model[i](y)
         y = self.model[i + 1](y)
         new_x = self.model[i + 2](y)

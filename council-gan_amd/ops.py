@@ -329,6 +329,89 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 
 
 # ------------------------------------------------------------------------------------------
+# split-precision ("fp16 x 3") forward path -- tape-free passes only
+# ------------------------------------------------------------------------------------------
+class SplitTensor:
+    """A tensor stored as two fp16 planes (hi = f16(s*v), lo = f16(s*v - hi)), physical NHWC / [O][KH][KW][I].
+    `buf` is a flat fp16 tensor; the hi plane starts at element `off`, the lo plane `lo` elements later; `scale` is
+    the power of two s the values were multiplied by (weights: hip.X3_WSCALE)."""
+
+    def __init__(self, buf, shape, off=0, lo=None, scale=1.0):
+        self.buf, self.shape, self.off, self.scale = buf, tuple(shape), off, scale
+        n = 1
+        for d in shape:
+            n *= d
+        self.numel = n
+        self.lo = n if lo is None else lo
+
+    def hi_ptr(self):
+        return c_void_p(self.buf.data_ptr() + 2 * self.off)
+
+
+def split_f16(x, scale=1.0):
+    """fp32 NCHW(channels_last) tensor -> SplitTensor"""
+    if torch.is_grad_enabled() and x.requires_grad:
+        raise hip.HipError("split-precision tensors carry no gradient: use them under torch.no_grad() only")
+    x = nhwc(x)
+    buf = torch.empty(2 * x.numel(), dtype=torch.float16, device=x.device)
+    check(_lib().cg_split_f16(ptr(x), ptr(buf), x.numel(), x.numel(), float(scale), stream()), "cg_split_f16")
+    return SplitTensor(buf, x.shape, scale=scale)
+
+
+def conv2d_x3(xs, wsplit, Cout, KH, KW, bias=None, stride=1, pad=0, act="none", upsample=False, stats=None):
+    """act(conv2d(zero_pad(x), W) + bias) on the fp16 MFMA with every product expanded as ah*bh + ah*bl + al*bh.
+    xs: SplitTensor activation; wsplit: SplitTensor over the physical [Cout][KH][KW][Cin] weight.  No autograd."""
+    if torch.is_grad_enabled() and (bias is not None and bias.requires_grad):
+        raise hip.HipError("conv2d_x3 has no backward: call it under torch.no_grad()")
+    lib = _lib()
+    N, C1, H, W = xs.shape
+    g = fwd_geom(N, H, W, C1, 0, int(bool(upsample)), KH, KW, stride, pad, Cout, ACT[act])
+    y = torch.empty((N, Cout, g.Ho, g.Wo), dtype=torch.float32, device=xs.buf.device, memory_format=CL)
+    rows = ctypes.c_int(0)
+    sws, sbytes, rp = None, 0, None
+    if stats is not None and ACT[act] == 0:
+        m = N * g.Ho * g.Wo
+        sws = workspace(((m + 63) // 64) * Cout * 16, slot=1)
+        sbytes, rp = sws.numel(), byref(rows)
+    if xs.scale != 1.0:
+        raise hip.HipError("conv2d_x3: activations must be split unscaled")
+    check(lib.cg_conv2d_fwd_x3(byref(g), xs.hi_ptr(), xs.lo, wsplit.hi_ptr(), wsplit.lo, float(wsplit.scale), ptr(bias), ptr(y),
+                               ptr(sws), sbytes, rp, -1, stream()), "cg_conv2d_fwd_x3")
+    if stats is not None and rows.value:
+        stats.append((sws, rows.value))
+    return y
+
+
+def instnorm_split(x, params, goff, boff, act="none", residual=None, eps=1e-5, stats=None, want_f32=False):
+    """IN / AdaIN apply (no autograd) whose output is produced in split form (and in fp32 too when `want_f32`:
+    the ResBlock skip connection and the fp32 consumers need it).  Returns (y_fp32_or_None, SplitTensor)."""
+    lib = _lib()
+    x, residual = nhwc(x), nhwc(residual)
+    N, C, H, W = x.shape
+    HW = H * W
+    mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    if stats:
+        part, rows = stats[0]
+        check(lib.cg_instnorm_stats_from_partials(ptr(part), N, HW, C, rows, eps, ptr(mean), ptr(rstd), stream()),
+              "cg_instnorm_stats_from_partials")
+    else:
+        ws = workspace(lib.cg_instnorm_workspace(N, HW, C))
+        check(lib.cg_instnorm_stats(ptr(x), N, HW, C, eps, ptr(mean), ptr(rstd), ptr(ws), ws.numel(), stream()),
+              "cg_instnorm_stats")
+    if params is not None:
+        params = params.contiguous()
+        gp, bp, gs = _off(params, goff), _off(params, boff), params.shape[1]
+    else:
+        gp, bp, gs = None, None, C
+    y = torch.empty_like(x) if want_f32 else None
+    ys = SplitTensor(torch.empty(2 * x.numel(), dtype=torch.float16, device=x.device), x.shape)
+    check(lib.cg_instnorm_apply_split(ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(residual), ptr(y), ys.hi_ptr(), ys.lo,
+                                      N, HW, C, ACT[act], stream()), "cg_instnorm_apply_split")
+    return y, ys
+
+
+# ------------------------------------------------------------------------------------------
 # resampling
 # ------------------------------------------------------------------------------------------
 class _AvgPool3s2(torch.autograd.Function):

@@ -182,6 +182,10 @@ class Council_Trainer(nn.Module):
         self._img_cache = {}
         self._enc_cache = {}
         self._streams = []
+        # precision of the tape-free decoder passes (the generated images the discriminator updates consume):
+        # "split" = fp16 x 3 MFMA (22 significand bits, 2.7-3x faster), "fp32" = exact fp32 MFMA everywhere
+        self._split_fwd = str(hp.get('cg_nograd_precision', os.environ.get('CG_NOGRAD_PRECISION', 'split'))) == 'split'
+        self._wsplit = {}
 
     # ------------------------------------------------------------------------------------
     # device placement
@@ -253,6 +257,39 @@ class Council_Trainer(nn.Module):
             self._img_cache[slot] = (x, x._version, y)     # holding `x` keeps its address from being recycled
         return y
 
+    def _refresh_split_weights(self, d, i):
+        """{hi, lo} fp16 planes of member i's generator weights (pre-scaled by hip.X3_WSCALE) for the split-precision
+        decoder passes of the two discriminator updates (ops.conv2d_x3): ONE kernel over the flat parameter buffer per
+        generator step."""
+        if not self._split_fwd:
+            return
+        opt = self.gen_opt_s[i]
+        key = (d, i)
+        ent = self._wsplit.get(key)
+        if ent is not None and ent[0] == opt.version:
+            return
+        f = opt.flat
+        total = f['data'].numel()
+        buf = ent[1] if ent is not None else torch.empty(2 * total, dtype=torch.float16, device=f['data'].device)
+        check(hip.load().cg_split_f16(ptr(f['data']), ptr(buf), total, total, hip.X3_WSCALE, stream()), "cg_split_f16")
+        offs = {id(p): o for p, o in zip(opt._params, f['offs'])}
+        for blk in self._nets('gen', d)[i].dec._split_blocks():
+            w = blk.conv.weight
+            blk._cg_wsplit = ops.SplitTensor(buf, (w.shape[0], w.shape[2], w.shape[3], w.shape[1]), off=offs[id(w)], lo=total,
+                                              scale=hip.X3_WSCALE)
+        self._wsplit[key] = (opt.version, buf)
+
+    @contextlib.contextmanager
+    def _split_decode(self, d, i):
+        """Scope in which member i's decoder may take the split-precision trunk (weights refreshed on entry)."""
+        self._refresh_split_weights(d, i)
+        dec = self._nets('gen', d)[i].dec
+        dec.split_active = self._split_fwd
+        try:
+            yield
+        finally:
+            dec.split_active = False
+
     def _weights_version(self, d, i):
         gen = self._nets('gen', d)[i]
         return (self.gen_opt_s[i].version, sum(p._version for p in gen.enc_content.parameters()))
@@ -313,7 +350,7 @@ class Council_Trainer(nn.Module):
                 for d in self._dirs:
                     gen = self._nets('gen', d)[i]
                     content = self._content(d, i, x[d], need_grad=False)
-                    with torch.no_grad():
+                    with torch.no_grad(), self._split_decode(d, i):
                         x_fake = gen.decode(content, s[d], x[d])
                     # :775-777 -- only the a2b term is scaled by gan_w (reference quirk, kept); the scale is
                     # folded into the per-sample loss weights
@@ -364,7 +401,7 @@ class Council_Trainer(nn.Module):
                 for d in self._dirs:
                     gen = self._nets('gen', d)[i]
                     content = self._content(d, i, x[d], need_grad=False)
-                    with torch.no_grad():
+                    with torch.no_grad(), self._split_decode(d, i):
                         x_full[d][i] = gen.decode(content, s[d], x[d])
                         x_cmp_local[d].append(gen.decode(content, s_less[d], x[d]) if less != 0 else x_full[d][i])
         self._join()      # every member's council discriminator reads the OTHER members' images

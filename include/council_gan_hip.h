@@ -78,6 +78,24 @@ int cg_conv2d_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const
 int cg_conv2d_fwd_stats(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
                         float* y, double* stats, size_t stats_bytes, int* rows_per_partial, cg_stream_t stream);
 
+/* ---- split-precision ("fp16 x 3") forward, for passes WITHOUT a gradient tape ----------
+ * cg_split_f16: out[0..n) = f16(scale*x), out[lo_elems..lo_elems+n) = f16(scale*x - hi), round-to-nearest-even.
+ * cg_conv2d_fwd_x3: y = act(conv(x) / w_scale + bias) with x and w given as such plane pairs (x: NHWC, w:
+ * [Cout][T][C] pre-multiplied by the power of two w_scale), a*b evaluated as ah*bh + ah*bl + al*bh on the fp16 MFMA
+ * with fp32 accumulation (22 significand bits: error at the level of the fp32 kernel's accumulation round-off);
+ * same geometry, epilogue and optional instance-norm partials as cg_conv2d_fwd_stats.  tile_cfg -1 = heuristic.
+ * The lo plane of an operand starts *_lo_elems halves after its hi plane. */
+#define CG_X3_WSCALE 1024.0f
+int cg_split_f16(const float* x, void* out, size_t n, size_t lo_elems, float scale, cg_stream_t stream);
+int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* x_hi, size_t x_lo_elems, const void* w_hi, size_t w_lo_elems,
+                     float w_scale, const float* bias, float* y, double* stats, size_t stats_bytes,
+                     int* rows_per_partial, int tile_cfg, cg_stream_t stream);
+/* instance norm / AdaIN apply that writes the split form of its output (and / or fp32): the producer side of
+ * cg_conv2d_fwd_x3.  y may be NULL (split only); y_split hi plane [N*HW*C], lo plane y_lo_elems further on. */
+int cg_instnorm_apply_split(const float* x, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, int gstride, const float* residual, float* y, void* y_split,
+                            size_t y_lo_elems, int N, int HW, int C, int act, cg_stream_t stream);
+
 /* Same, with the block-tile configuration forced (tuning / A-B benchmarking hook; -1 = heuristic). */
 int cg_conv2d_fwd_tile(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
                        const float* bias, float* y, int tile_cfg, cg_stream_t stream);
@@ -197,7 +215,7 @@ int cg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
  * HIP events recorded on the launch stream.  cg_prof_collect() synchronises them and returns, per
  * kernel slot (slot = kernel family * 16 + tile shape * 2 + fast-path flag; see cg_prof_slot_name),
  * launch count, total milliseconds and total algorithmic FLOPs (2*M*N*K of each launch). */
-#define CG_PROF_SLOTS 64
+#define CG_PROF_SLOTS 80
 int cg_prof_enable(int on);
 int cg_prof_collect(int64_t* counts, double* ms, double* flops);
 const char* cg_prof_slot_name(int slot);
