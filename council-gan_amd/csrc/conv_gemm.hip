@@ -1410,11 +1410,13 @@ extern "C" int cg_split_f16(const float* x, void* out, size_t n, size_t lo_elems
 }
 
 extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_lo_elems, const void* ws,
-                                size_t w_lo_elems, float w_scale, const float* bias, float* y, double* stats,
-                                size_t stats_bytes, int* rows_per_partial, int tile_cfg, cg_stream_t stream) {
+                                size_t w_lo_elems, float w_scale, const float* bias, float* y, void* y_split,
+                                size_t y_lo_elems, double* stats, size_t stats_bytes, int* rows_per_partial,
+                                int tile_cfg, cg_stream_t stream) {
     int rc = validate_geom(g, "cg_conv2d_fwd_x3");
     if (rc) return rc;
     CG_CHECK_ARG(xs && ws && y && w_scale > 0.f, "cg_conv2d_fwd_x3: null pointer / bad scale");
+    CG_CHECK_ARG(!y_split || y_lo_elems >= (size_t)g->N * g->HoF * g->WoF * g->Cout, "cg_conv2d_fwd_x3: y lo plane overlaps");
     const int K = g->T * g->C1;
     const int M = g->N * g->Ho * g->Wo;
     const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, w_plane = (size_t)g->Cout * K * 2;
@@ -1446,10 +1448,10 @@ extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_
     hipStream_t st = cg_s(stream);
     const unsigned xl = (unsigned)(x_lo_elems * 2), xsp = (unsigned)x_span;
     switch (cfg) {
-        case 0: return launch_x3<128, 128, 64, 64>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr);   // 4 waves
-        case 1: return launch_x3<128, 128, 64, 32>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr);   // 8 waves
-        case 2: return launch_x3<128, 64, 32, 32>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr);    // 8 waves
-        case 3: return launch_x3<64, 64, 32, 32>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr);     // 4 waves
+        case 0: return launch_x3<128, 128, 64, 64>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr, y_split, y_lo_elems);   // 4 waves
+        case 1: return launch_x3<128, 128, 64, 32>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr, y_split, y_lo_elems);   // 8 waves
+        case 2: return launch_x3<128, 64, 32, 32>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr, y_split, y_lo_elems);    // 8 waves
+        case 3: return launch_x3<64, 64, 32, 32>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr, y_split, y_lo_elems);     // 4 waves
         default: return cg_set_error(CG_ERR_ARG, "cg_conv2d_fwd_x3: unknown tile configuration %d", cfg);
     }
 }

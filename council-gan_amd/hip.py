@@ -38,8 +38,8 @@ _SIGS = {
     "cg_conv2d_fwd_stats": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_size_t, POINTER(c_int), _P]),
     "cg_instnorm_stats_from_partials": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "cg_split_f16": (c_int, [_P, _P, c_size_t, c_size_t, c_float, _P]),
-    "cg_conv2d_fwd_x3": (c_int, [POINTER(ConvGeom), _P, c_size_t, _P, c_size_t, c_float, _P, _P, _P, c_size_t, POINTER(c_int),
-                                 c_int, _P]),
+    "cg_conv2d_fwd_x3": (c_int, [POINTER(ConvGeom), _P, c_size_t, _P, c_size_t, c_float, _P, _P, _P, c_size_t, _P, c_size_t,
+                                 POINTER(c_int), c_int, _P]),
     "cg_instnorm_apply_split": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, _P]),
     "cg_conv2d_fwd_tile": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P]),
     "cg_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvGeom)]),

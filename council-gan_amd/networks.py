@@ -44,9 +44,10 @@ class AdaptiveInstanceNorm2d(nn.Module):
         self.register_buffer('running_mean', torch.zeros(num_features))
         self.register_buffer('running_var', torch.ones(num_features))
 
-    def forward(self, x, act='none', residual=None, stats=None):
+    def forward(self, x, act='none', residual=None, stats=None, want_split=False):
         assert self.params is not None, "Please assign weight and bias before calling AdaIN!"
-        return ops.adain(x, self.params, self.goff, self.boff, act=act, residual=residual, eps=self.eps, stats=stats)
+        return ops.adain(x, self.params, self.goff, self.boff, act=act, residual=residual, eps=self.eps, stats=stats,
+                         want_split=want_split)
 
     def __repr__(self):
         return self.__class__.__name__ + '(' + str(self.num_features) + ')'
@@ -108,12 +109,16 @@ class Conv2dBlock(nn.Module):
         act = self.activation_type
         fused_act = act if self.norm is None else 'none'
         stats = [] if self.norm_type in ('in', 'adain') else None     # conv epilogue -> norm statistics hand-off
+        # split-precision forward (ops.conv2d): the layer's output also leaves in {hi, lo} fp16 form when the next
+        # convolution can consume it (its input width = this layer's output width)
+        wmgr = getattr(self, '_cg_wmgr', None)
+        want_split = wmgr is not None and self.conv.out_channels % 32 == 0
         y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, fused_act, x2=x2,
-                       upsample=upsample, stats=stats)
+                       upsample=upsample, stats=stats, wmgr=wmgr, want_split=want_split)
         if self.norm_type == 'in':
-            y = ops.instance_norm(y, act=act, residual=residual, eps=self.norm.eps, stats=stats)
+            y = ops.instance_norm(y, act=act, residual=residual, eps=self.norm.eps, stats=stats, want_split=want_split)
         elif self.norm_type == 'adain':
-            y = self.norm(y, act=act, residual=residual, stats=stats)
+            y = self.norm(y, act=act, residual=residual, stats=stats, want_split=want_split)
         elif self.norm_type == 'ln':
             y = ops.activation(self.norm(y), act)
             if residual is not None:
@@ -454,7 +459,7 @@ class MsImageDis(nn.Module):
             for blk in list(model)[:-1]:
                 y = blk(y)
             last = model[len(model) - 1]
-            outputs.append(ops.conv2d(y, last.weight, last.bias, 1, 0, 'none'))
+            outputs.append(ops.conv2d(y, last.weight, last.bias, 1, 0, 'none', wmgr=getattr(self, '_cg_wmgr', None)))
             if si + 1 < len(self.cnns):
                 x = ops.avgpool3s2(x)
         return outputs
@@ -516,8 +521,9 @@ class MsImageDisCouncil(nn.Module):
             y = blocks[0](x, x2=x_input)
             for blk in blocks[1:-2]:
                 y = blk(y)
-            y = ops.conv2d(y, blocks[-2].weight, blocks[-2].bias, 1, 0, 'none')
-            outputs.append(ops.conv2d(y, blocks[-1].weight, blocks[-1].bias, 1, 0, 'none'))
+            wmgr = getattr(self, '_cg_wmgr', None)
+            y = ops.conv2d(y, blocks[-2].weight, blocks[-2].bias, 1, 0, 'none', wmgr=wmgr, want_split=wmgr is not None)
+            outputs.append(ops.conv2d(y, blocks[-1].weight, blocks[-1].bias, 1, 0, 'none', wmgr=wmgr))
             if si + 1 < len(self.cnns):
                 x = ops.avgpool3s2(x)
                 x_input = ops.avgpool3s2(x_input)

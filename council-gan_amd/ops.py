@@ -103,7 +103,8 @@ class _Conv2d(torch.autograd.Function):
     """act(conv2d(zero_pad(x (++ x2)), weight) + bias); networks.py:515-521 without the norm."""
 
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, wgrad_buf, bgrad_buf, stride, pad, act, up, stats):
+    def forward(ctx, x, x2, weight, bias, wgrad_buf, bgrad_buf, stride, pad, act, up, stats, xsplit=None, wsplit=None,
+                out_split=None):
         lib = _lib()
         x, x2, w = nhwc(x), nhwc(x2), nhwc(weight)
         N, C1, H, W = x.shape
@@ -115,7 +116,24 @@ class _Conv2d(torch.autograd.Function):
             raise ValueError("concat sources must agree in N, H, W")
         g = fwd_geom(N, H, W, C1, C2, int(up), KH, KW, stride, pad, Cout, act)
         y = empty_nhwc(N, Cout, g.Ho, g.Wo, x)
-        if stats is not None and act == 0:
+        if xsplit is not None and wsplit is not None and x3_eligible(C1, C2):
+            # split-precision forward (fp16 x 3 MFMA, 22 significand bits); the backward below is unchanged and reads
+            # the fp32 operands saved on the tape
+            rows = ctypes.c_int(0)
+            sws, sbytes, rp = None, 0, None
+            if stats is not None and act == 0:
+                sws = workspace(((N * g.Ho * g.Wo + 63) // 64) * Cout * 16, slot=1)
+                sbytes, rp = sws.numel(), byref(rows)
+            ysp = None
+            if out_split is not None:
+                ysp = SplitTensor(torch.empty(2 * y.numel(), dtype=torch.float16, device=y.device), y.shape)
+                out_split.append(ysp)
+            check(lib.cg_conv2d_fwd_x3(byref(g), xsplit.hi_ptr(), xsplit.lo, wsplit.hi_ptr(), wsplit.lo, float(wsplit.scale),
+                                       ptr(bias), ptr(y), ysp.hi_ptr() if ysp else None, ysp.lo if ysp else 0, ptr(sws), sbytes,
+                                       rp, -1, stream()), "cg_conv2d_fwd_x3")
+            if stats is not None and rows.value:
+                stats.append((sws, rows.value))
+        elif stats is not None and act == 0:
             # an instance norm follows: let the conv epilogue emit its partial sums (ops.instance_norm consumes them)
             m = N * g.Ho * g.Wo
             sws = workspace(((m + 63) // 64) * Cout * 16, slot=1)
@@ -164,16 +182,37 @@ class _Conv2d(torch.autograd.Function):
         dx2 = None
         if x2 is not None and ctx.needs_input_grad[1]:
             dx2 = conv_dgrad(g, dz, w, x.shape[1], x2.shape[1])
-        return dx, dx2, dw, db, None, None, None, None, None, None, None
+        return dx, dx2, dw, db, None, None, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=False, stats=None):
+X3_FORWARD = True     # module switch (Council_Trainer sets it from the config): split-precision forward convolutions
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=False, stats=None, wmgr=None,
+           want_split=False):
     """Functional conv.  `weight` may be an nn.Parameter managed by a flat optimizer buffer.  `stats`: an empty
     list when an instance norm consumes the output next -- the conv appends (partials, rows) if its epilogue
-    produced the norm's partial sums (pass the same list to instance_norm / adain)."""
-    return _Conv2d.apply(x, x2, weight, bias, getattr(weight, "_cg_grad", None),
-                         getattr(bias, "_cg_grad", None) if bias is not None else None,
-                         int(stride), int(pad), ACT[act], bool(upsample), stats)
+    produced the norm's partial sums (pass the same list to instance_norm / adain).
+    `wmgr` (SplitWeights): run the FORWARD on the split-precision kernel when the layer qualifies; the input's
+    split form travels as the `_cg_split` attribute of `x` (set by the op that produced it), and with `want_split`
+    the output gets one for the next convolution."""
+    xsplit = wsplit = out_split = None
+    if X3_FORWARD and wmgr is not None and x2 is None and x3_eligible(x.shape[1], 0) and weight.dim() == 4:
+        # only inputs whose producer emitted the split form qualify: those are instance-normalised (or one fused
+        # conv+ReLU away from it), i.e. O(1) activations inside fp16's accurate range -- an arbitrary-scale tensor
+        # would need a per-tensor power-of-two scale first (DESIGN.md section 4.5)
+        xsplit = getattr(x, "_cg_split", None)
+        wsplit = wmgr.get(weight) if xsplit is not None else None
+        if wsplit is None:
+            xsplit = None
+        elif want_split and stats is None:        # with a norm next, the norm's apply pass emits the split form
+            out_split = []
+    y = _Conv2d.apply(x, x2, weight, bias, getattr(weight, "_cg_grad", None),
+                      getattr(bias, "_cg_grad", None) if bias is not None else None,
+                      int(stride), int(pad), ACT[act], bool(upsample), stats, xsplit, wsplit, out_split)
+    if out_split:
+        y._cg_split = out_split[0]
+    return y
 
 
 def linear(x, weight, bias=None, act="none"):
@@ -181,7 +220,8 @@ def linear(x, weight, bias=None, act="none"):
     n = x.shape[0]
     w4 = weight.view(weight.shape[0], weight.shape[1], 1, 1)
     y = _Conv2d.apply(x.reshape(n, -1, 1, 1), None, w4, bias, getattr(weight, "_cg_grad", None),
-                      getattr(bias, "_cg_grad", None) if bias is not None else None, 1, 0, ACT[act], False, None)
+                      getattr(bias, "_cg_grad", None) if bias is not None else None, 1, 0, ACT[act], False, None, None, None,
+                      None)
     return y.reshape(n, -1)
 
 
@@ -193,7 +233,7 @@ class _InstNormAct(torch.autograd.Function):
     of `params` ([N, P], the MLP output, networks.py:303-312) or absent (plain nn.InstanceNorm2d)."""
 
     @staticmethod
-    def forward(ctx, x, params, goff, boff, residual, act, eps, stats):
+    def forward(ctx, x, params, goff, boff, residual, act, eps, stats, out_split=None):
         lib = _lib()
         x, residual = nhwc(x), nhwc(residual)
         N, C, H, W = x.shape
@@ -216,8 +256,14 @@ class _InstNormAct(torch.autograd.Function):
             gp, bp, gs = _off(params, goff), _off(params, boff), params.shape[1]
         else:
             gp, bp, gs = None, None, C
-        check(lib.cg_instnorm_apply(ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(residual), ptr(y), N, HW, C, act,
-                                    stream()), "cg_instnorm_apply")
+        if out_split is not None and (C & 3) == 0 and 256 % (C >> 2) == 0:
+            ysp = SplitTensor(torch.empty(2 * y.numel(), dtype=torch.float16, device=y.device), y.shape)
+            check(lib.cg_instnorm_apply_split(ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(residual), ptr(y), ysp.hi_ptr(),
+                                              ysp.lo, N, HW, C, act, stream()), "cg_instnorm_apply_split")
+            out_split.append(ysp)
+        else:
+            check(lib.cg_instnorm_apply(ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(residual), ptr(y), N, HW, C, act,
+                                        stream()), "cg_instnorm_apply")
         ctx.save_for_backward(x, mean, rstd, params)
         ctx.meta = (goff, boff, act, residual is not None)
         return y
@@ -246,15 +292,23 @@ class _InstNormAct(torch.autograd.Function):
             gs = C
         check(lib.cg_instnorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(dx), dgp, dbp, N, HW, C, act,
                                   ptr(ws), ws.numel(), stream()), "cg_instnorm_bwd")
-        return dx, dparams, None, None, (dy if has_res else None), None, None, None
+        return dx, dparams, None, None, (dy if has_res else None), None, None, None, None
 
 
-def instance_norm(x, act="none", residual=None, eps=1e-5, stats=None):
-    return _InstNormAct.apply(x, None, 0, 0, residual, ACT[act], float(eps), stats)
+def _norm_apply(x, params, goff, boff, residual, act, eps, stats, want_split):
+    out_split = [] if (want_split and X3_FORWARD) else None
+    y = _InstNormAct.apply(x, params, goff, boff, residual, ACT[act], float(eps), stats, out_split)
+    if out_split:
+        y._cg_split = out_split[0]
+    return y
 
 
-def adain(x, params, goff, boff, act="none", residual=None, eps=1e-5, stats=None):
-    return _InstNormAct.apply(x, params, int(goff), int(boff), residual, ACT[act], float(eps), stats)
+def instance_norm(x, act="none", residual=None, eps=1e-5, stats=None, want_split=False):
+    return _norm_apply(x, None, 0, 0, residual, act, eps, stats, want_split)
+
+
+def adain(x, params, goff, boff, act="none", residual=None, eps=1e-5, stats=None, want_split=False):
+    return _norm_apply(x, params, int(goff), int(boff), residual, act, eps, stats, want_split)
 
 
 class _Activation(torch.autograd.Function):
@@ -348,6 +402,41 @@ class SplitTensor:
         return c_void_p(self.buf.data_ptr() + 2 * self.off)
 
 
+class SplitWeights:
+    """{hi, lo} fp16 planes of ALL parameters of one flat optimizer (optim.FlatAdam), pre-scaled by hip.X3_WSCALE and
+    re-split lazily -- one kernel over the flat buffer -- whenever the optimizer's `version` moved (a step, a
+    checkpoint load).  `get(weight)` returns the SplitTensor view of one conv weight, or None for tensors the
+    optimizer does not own."""
+
+    def __init__(self, opt):
+        self.opt = opt
+        self.version = None
+        self.buf = None
+        self.views = {}
+
+    def get(self, weight):
+        opt = self.opt
+        if opt._flat is None:
+            return None
+        if self.version != opt.version:
+            f = opt.flat
+            total = f['data'].numel()
+            if self.buf is None or self.buf.numel() != 2 * total or self.buf.device != f['data'].device:
+                self.buf = torch.empty(2 * total, dtype=torch.float16, device=f['data'].device)
+            check(_lib().cg_split_f16(ptr(f['data']), ptr(self.buf), total, total, hip.X3_WSCALE, stream()), "cg_split_f16")
+            self.views = {}
+            for p, o in zip(opt._params, f['offs']):
+                if p.dim() == 4:
+                    self.views[id(p)] = SplitTensor(self.buf, (p.shape[0], p.shape[2], p.shape[3], p.shape[1]), off=o, lo=total,
+                                                    scale=hip.X3_WSCALE)
+            self.version = opt.version
+        return self.views.get(id(weight))
+
+
+def x3_eligible(C1, C2):
+    return C2 == 0 and C1 % 32 == 0
+
+
 def split_f16(x, scale=1.0):
     """fp32 NCHW(channels_last) tensor -> SplitTensor"""
     if torch.is_grad_enabled() and x.requires_grad:
@@ -376,7 +465,7 @@ def conv2d_x3(xs, wsplit, Cout, KH, KW, bias=None, stride=1, pad=0, act="none", 
     if xs.scale != 1.0:
         raise hip.HipError("conv2d_x3: activations must be split unscaled")
     check(lib.cg_conv2d_fwd_x3(byref(g), xs.hi_ptr(), xs.lo, wsplit.hi_ptr(), wsplit.lo, float(wsplit.scale), ptr(bias), ptr(y),
-                               ptr(sws), sbytes, rp, -1, stream()), "cg_conv2d_fwd_x3")
+                               None, 0, ptr(sws), sbytes, rp, -1, stream()), "cg_conv2d_fwd_x3")
     if stats is not None and rows.value:
         stats.append((sws, rows.value))
     return y

@@ -46,17 +46,22 @@ class FlatAdam(torch.optim.Optimizer):
         if self._flat is not None and self._flat["data"].device == device:
             return
         sizes = [p.numel() for p in self._params]
-        total = sum(sizes)
+        # every parameter starts on a 32-byte boundary of the flat buffers, so that the fp16 {hi, lo} mirror of the
+        # buffer (ops.SplitWeights) is 16-byte aligned per tensor (buffer_load_dwordx4); padding stays zero for ever
+        starts, total = [], 0
+        for n in sizes:
+            starts.append(total)
+            total = (total + n + 7) & ~7
         old = self._flat
-        data = torch.empty(total, dtype=torch.float32, device=device)
+        data = torch.zeros(total, dtype=torch.float32, device=device)
         grad = torch.zeros(total, dtype=torch.float32, device=device)
         m = torch.zeros(total, dtype=torch.float32, device=device)
         v = torch.zeros(total, dtype=torch.float32, device=device)
         if old is not None:
             m.copy_(old["m"])
             v.copy_(old["v"])
-        offs, off = [], 0
-        for p, n in zip(self._params, sizes):
+        offs = []
+        for p, n, off in zip(self._params, sizes, starts):
             view = _phys_view(data, off, tuple(p.shape))
             view.copy_(p.data)
             p.data = view
@@ -65,7 +70,6 @@ class FlatAdam(torch.optim.Optimizer):
             p._cg_grad = g
             p.grad = g
             offs.append(off)
-            off += n
         self._flat = dict(data=data, grad=grad, m=m, v=v, offs=offs, sizes=sizes)
         self.version += 1
 

@@ -182,10 +182,10 @@ class Council_Trainer(nn.Module):
         self._img_cache = {}
         self._enc_cache = {}
         self._streams = []
-        # precision of the tape-free decoder passes (the generated images the discriminator updates consume):
-        # "split" = fp16 x 3 MFMA (22 significand bits, 2.7-3x faster), "fp32" = exact fp32 MFMA everywhere
-        self._split_fwd = str(hp.get('cg_nograd_precision', os.environ.get('CG_NOGRAD_PRECISION', 'split'))) == 'split'
-        self._wsplit = {}
+        # precision of the FORWARD convolutions (every backward kernel is exact fp32 MFMA): "split" = fp16 x 3 MFMA on
+        # {hi, lo} fp16 operand planes (22 significand bits -- error below the fp32 kernel's accumulation round-off --
+        # at 2.5-2.8x its rate), "fp32" = fp32 MFMA everywhere
+        self._split_fwd = str(hp.get('cg_forward_precision', os.environ.get('CG_FORWARD_PRECISION', 'split'))) == 'split'
 
     # ------------------------------------------------------------------------------------
     # device placement
@@ -217,6 +217,21 @@ class Council_Trainer(nn.Module):
         # Council members are independent models: each local member's kernels go to its own HIP stream, so the
         # low-occupancy launches of one member (16x16 / 8x8 discriminator layers, 1-block-per-CU convs) overlap with
         # another member's work.  CG_MEMBER_STREAMS=1 serialises everything on the caller's stream.
+        # split-precision forward convolutions in the GENERATORS (instance-normalised activations: inside fp16's
+        # accurate range by construction; the un-normalised discriminators stay on fp32 MFMA): one lazily refreshed
+        # {hi, lo} fp16 copy of the generator optimizer's weights
+        ops.X3_FORWARD = self._split_fwd
+        if self._split_fwd:
+            for i in self.shard.local:
+                for kind, opt in (('gen', self.gen_opt_s[i]),):
+                    mgr = ops.SplitWeights(opt)
+                    for d in self._dirs:
+                        net = self._nets(kind, d)[i]
+                        for m in net.modules():
+                            m._cg_wmgr = mgr
+                        # a checkpoint load rewrites the weights behind the optimizer's back: invalidate the copies
+                        net.register_load_state_dict_post_hook(
+                            lambda module, keys, _opt=opt: setattr(_opt, 'version', _opt.version + 1))
         n = min(int(os.environ.get('CG_MEMBER_STREAMS', '2')), len(self.shard.local))
         self._streams = [torch.cuda.Stream(device=dev) for _ in range(n)] if n > 1 else []
         return self
@@ -258,26 +273,12 @@ class Council_Trainer(nn.Module):
         return y
 
     def _refresh_split_weights(self, d, i):
-        """{hi, lo} fp16 planes of member i's generator weights (pre-scaled by hip.X3_WSCALE) for the split-precision
-        decoder passes of the two discriminator updates (ops.conv2d_x3): ONE kernel over the flat parameter buffer per
-        generator step."""
+        """Point the decoder's split-precision trunk at the current {hi, lo} fp16 weights (ops.SplitWeights re-splits
+        the generator's flat parameter buffer lazily, once per generator step)."""
         if not self._split_fwd:
             return
-        opt = self.gen_opt_s[i]
-        key = (d, i)
-        ent = self._wsplit.get(key)
-        if ent is not None and ent[0] == opt.version:
-            return
-        f = opt.flat
-        total = f['data'].numel()
-        buf = ent[1] if ent is not None else torch.empty(2 * total, dtype=torch.float16, device=f['data'].device)
-        check(hip.load().cg_split_f16(ptr(f['data']), ptr(buf), total, total, hip.X3_WSCALE, stream()), "cg_split_f16")
-        offs = {id(p): o for p, o in zip(opt._params, f['offs'])}
         for blk in self._nets('gen', d)[i].dec._split_blocks():
-            w = blk.conv.weight
-            blk._cg_wsplit = ops.SplitTensor(buf, (w.shape[0], w.shape[2], w.shape[3], w.shape[1]), off=offs[id(w)], lo=total,
-                                              scale=hip.X3_WSCALE)
-        self._wsplit[key] = (opt.version, buf)
+            blk._cg_wsplit = blk._cg_wmgr.get(blk.conv.weight)
 
     @contextlib.contextmanager
     def _split_decode(self, d, i):

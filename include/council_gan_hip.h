@@ -88,8 +88,10 @@ int cg_conv2d_fwd_stats(const cg_conv_geom* g, const float* x1, const float* x2,
 #define CG_X3_WSCALE 1024.0f
 int cg_split_f16(const float* x, void* out, size_t n, size_t lo_elems, float scale, cg_stream_t stream);
 int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* x_hi, size_t x_lo_elems, const void* w_hi, size_t w_lo_elems,
-                     float w_scale, const float* bias, float* y, double* stats, size_t stats_bytes,
-                     int* rows_per_partial, int tile_cfg, cg_stream_t stream);
+                     float w_scale, const float* bias, float* y, void* y_split, size_t y_lo_elems, double* stats,
+                     size_t stats_bytes, int* rows_per_partial, int tile_cfg, cg_stream_t stream);
+/* y_split (optional): the output ALSO in split form (hi plane, lo plane y_lo_elems halves later) for a convolution
+ * that consumes it next */
 /* instance norm / AdaIN apply that writes the split form of its output (and / or fp32): the producer side of
  * cg_conv2d_fwd_x3.  y may be NULL (split only); y_split hi plane [N*HW*C], lo plane y_lo_elems further on. */
 int cg_instnorm_apply_split(const float* x, const float* mean, const float* rstd, const float* gamma,

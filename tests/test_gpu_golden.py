@@ -333,9 +333,14 @@ def test_split_precision_decoder_matches_fp32(cga):
     s = torch.randn(2, 64, 1, 1).cuda()
     gen = tr.gen_a2b_s[0]
     with torch.no_grad():
+        cga.ops.X3_FORWARD = False                 # exact-fp32 reference: fp32 MFMA in every convolution
         c = gen.encode_content(x)
         ref_img = gen.decode(c, s, x).clone()
         ref_mask = gen.dec.mask_s.clone()
+        cga.ops.X3_FORWARD = True
+        c3 = gen.encode_content(x)                 # split-precision forward of the (tape-capable) general path
+        e_c = float((c3 - c).abs().max() / c.abs().max())
+        assert 0 < e_c < 2e-4, e_c
         with tr._split_decode('a2b', 0):
             assert gen.dec.split_active
             img = gen.decode(c, s, x)
@@ -346,9 +351,10 @@ def test_split_precision_decoder_matches_fp32(cga):
     e_mask = float((mask - ref_mask).abs().max() / ref_mask.abs().max())
     print("\n[split-precision decoder vs fp32] image %.2e  mask %.2e" % (e_img, e_mask))
     assert e_img < 2e-4 and e_mask < 2e-4, (e_img, e_mask)
-    # a generator step invalidates the split weights: the next scope must re-split them
-    v0 = tr._wsplit[('a2b', 0)][0]
+    # a generator step invalidates the split weights: the next use must re-split them
+    mgr = gen.dec._split_blocks()[0]._cg_wmgr
+    v0 = mgr.version
     tr.dis_update(x_a, x_a, cfg); tr.dis_council_update(x_a, x_a, cfg); tr.gen_update(x_a, x_a, cfg, 60000)
     with tr._split_decode('a2b', 0):
         pass
-    assert tr._wsplit[('a2b', 0)][0] != v0
+    assert mgr.version != v0 and mgr.version == tr.gen_opt_s[0].version

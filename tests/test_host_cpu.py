@@ -149,7 +149,9 @@ def test_flat_adam_views_and_state_dict_on_host():
     opt = cga.FlatAdam(params, lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-4)
     opt.materialize('cpu')
     f = opt.flat
-    assert f["data"].numel() == sum(p.numel() for p in params)
+    # every parameter starts on a 32-byte (8-element) boundary of the flat buffer; the padding is zero
+    assert all(o % 8 == 0 for o in f["offs"]) and f["offs"] == [0, 288, 296, 312]
+    assert f["data"].numel() == 320 and float(f["data"][312 + 3:].abs().sum()) == 0.0
     for p, b in zip(params, before):
         assert torch.equal(p.detach(), b)
         assert p.data.untyped_storage().data_ptr() == f["data"].untyped_storage().data_ptr()
