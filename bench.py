@@ -34,6 +34,11 @@ import torch.distributed as dist  # noqa: E402
 import yaml  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+F16X3_PEAK_TFLOPS = 2500.0 / 3    # split-precision kernels: dense fp16 MFMA peak / 3 MFMA passes per product
+
+
+def kernel_peak(name):
+    return F16X3_PEAK_TFLOPS if "_x3_" in name else FP32_MFMA_PEAK_TFLOPS
 
 # per-forward GFLOP at sigma = B*(H/128)^2 = 1 (hooks on every Conv2d/Linear)
 _S, _A, _D, _P, _Q, _c1, _p1, _q1 = 3.127, 14.535, 19.621, 1.038, 4.336, 0.308, 0.031, 0.142
@@ -156,7 +161,12 @@ def main():
                                "(train.py:237-251), fp32, all Adam steps" % (args.config.split('_')[0], args.size,
                                                                                args.size, council, args.batch),
                    "members_per_gpu": council // world, "member_images_per_sec": round(value * council, 3),
-                   "algorithmic_tflop_per_step": round(wmin, 3)},
+                   "algorithmic_tflop_per_step": round(wmin, 3),
+                   "forward_precision": ("generator forward convs: fp16x3 split-precision MFMA on {hi,lo} fp16 planes, "
+                                         "22 significand bits, fp32 accumulate (error below the fp32 kernel's round-off); "
+                                         "every backward and discriminator contraction: fp32 MFMA"
+                                         if trainer._split_fwd else "fp32 MFMA everywhere"),
+                   "member_streams": len(trainer._streams) or 1},
     }
 
     if rank == 0 and world == 1:
@@ -165,18 +175,21 @@ def main():
         # launches) from rocprofv3 PMC passes -- 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, profiles/r01_conv_pmc_probe.txt;
         # the algorithmic bytes of that shape are 36.0e6 (activations 16.8 + weights 2.4 + output 16.8 MB)
         roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "traffic": 53.3e6,
-                "step_achieved": round(step_tflops, 2), "step_frac": round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4)}
+                "step_achieved": round(step_tflops, 2), "step_frac": round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                "step_note": "W_min / step time against the fp32-MFMA peak; the step mixes fp32 and fp16x3 kernels"}
         if not args.no_kernel_profile:
             # one more iteration with HIP events around every MFMA conv launch (on the launch stream)
+            streams, trainer._streams = trainer._streams, []     # serialised: a launch's events see only that launch
             cga.hip.prof_enable(True)
             step(args.warmup + args.steps)
             torch.cuda.synchronize()
             prof = cga.hip.prof_collect()
             cga.hip.prof_enable(False)
+            trainer._streams = streams
             if args.shape_report:
                 open(args.shape_report, "w").write(cga.hip.prof_report())
             kernels = {k: {"launches": c, "avg_us": round(1000.0 * ms / c, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
-                           "share_of_conv_time": 0.0} for k, (c, ms, fl) in prof.items()}
+                           "peak": round(kernel_peak(k), 1), "share_of_conv_time": 0.0} for k, (c, ms, fl) in prof.items()}
             tot_ms = sum(ms for _, ms, _ in prof.values())
             tot_fl = sum(fl for _, _, fl in prof.values())
             for k, (c, ms, fl) in prof.items():
@@ -184,7 +197,8 @@ def main():
             dom = max(prof.items(), key=lambda kv: kv[1][1])
             dname, (dc, dms, dfl) = dom
             ach = dfl / (dms * 1e-3) / 1e12
-            roof.update({"kernel": dname, "achieved": round(ach, 2), "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+            roof.update({"kernel": dname, "achieved": round(ach, 2), "peak": round(kernel_peak(dname), 1),
+                         "frac": round(ach / kernel_peak(dname), 4),
                          "avg_launch_us": round(1000.0 * dms / dc, 2), "launches_per_step": dc,
                          "all_conv_kernels_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                          "conv_ms_per_step": round(tot_ms, 2), "executed_conv_tflop_per_step": round(tot_fl / 1e12, 3),

@@ -1257,8 +1257,9 @@ int pick_fwd_cfg(const cg_conv_geom* g, int M, bool pipe) {
     if (g->Cout > 32) {
         // 64 output channels: 8 waves of 32x32 on a 128x64 tile beat 4 waves of 64x32 by 4-6 % (two waves per SIMD);
         // short-K (1x1) layers are bandwidth-bound and prefer the smaller tile (profiles/r01_conv_tiles_pipe.txt)
-        if ((M + 127) / 128 < 192 || g->T * (g->C1 + g->C2) <= 128) return pipe ? 23 : 3;
-        return pipe ? 25 : 1;
+        if ((M + 127) / 128 < 192) return pipe ? 23 : 3;
+        if (pipe) return g->T * g->C1 <= 128 ? 23 : 25;
+        return 1;
     }
     return 2;
 }
