@@ -1030,6 +1030,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+__device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l);   // conv_x3.inc
+
 // Weight re-layout for the data-gradient passes.  Entry z of the table moves one tap:
 //   out[dst_base[z] + (ci * dst_T[z] + dst_tc[z]) * Cout + co] = w[(co * T + src_tap[z]) * Cin + ci0 + ci]
 // (one 32x32 LDS-tiled transpose per tap and 32x32 (ci, co) patch)
@@ -1045,8 +1047,10 @@ struct TransArgs {  // the kernel's kernarg layout (for the offset of the table)
     int32_t Cout, T, Cin, ci0, nci;
     TransTable tt;
 };
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ out,
-                                                               int Cout, int T, int Cin, int ci0, int nci, TransTable tt) {
+                                                               int Cout, int T, int Cin, int ci0, int nci, TransTable tt,
+                                                               float scale, unsigned lo_elems) {
     __shared__ float tile[32][33];
     typedef const __attribute__((address_space(4))) int32_t* KI;
     KI tab = (KI)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
@@ -1062,7 +1066,17 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         int ci = cib + r, co = cob + tx;
-        if (ci < nci && co < Cout) out[(size_t)base + ((size_t)ci * Tc + tc) * Cout + co] = tile[tx][r];
+        if (ci < nci && co < Cout) {
+            const size_t o = (size_t)base + ((size_t)ci * Tc + tc) * Cout + co;
+            if constexpr (SPLIT) {      // {hi, lo} fp16 planes of scale * w for the split-precision data-gradient
+                _Float16 h, l;
+                split_f16(tile[tx][r] * scale, h, l);
+                reinterpret_cast<_Float16*>(out)[o] = h;
+                reinterpret_cast<_Float16*>(out)[lo_elems + o] = l;
+            } else {
+                out[o] = tile[tx][r];
+            }
+        }
     }
 }
 
@@ -1411,9 +1425,9 @@ extern "C" int cg_split_f16(const float* x, void* out, size_t n, size_t lo_elems
 }
 
 extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_lo_elems, const void* ws,
-                                size_t w_lo_elems, float w_scale, const float* bias, float* y, void* y_split,
-                                size_t y_lo_elems, double* stats, size_t stats_bytes, int* rows_per_partial,
-                                int tile_cfg, cg_stream_t stream) {
+                                size_t w_lo_elems, float w_scale, const float* x_scale_dev, const float* bias, float* y,
+                                void* y_split, size_t y_lo_elems, double* stats, size_t stats_bytes,
+                                int* rows_per_partial, int tile_cfg, cg_stream_t stream) {
     int rc = validate_geom(g, "cg_conv2d_fwd_x3");
     if (rc) return rc;
     CG_CHECK_ARG(xs && ws && y && w_scale > 0.f, "cg_conv2d_fwd_x3: null pointer / bad scale");
@@ -1429,13 +1443,7 @@ extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_
     fill_class(b.c[0], g, (const float*)ws);
     b.c[0].w_bytes = (unsigned)(w_lo_elems * 2);
     b.c[0].pad_ = (int32_t)w_span;
-    int cfg = tile_cfg;
-    if (cfg < 0) {
-        // measured (profiles/r01_x3.txt): 8 waves of 64x32 on 128x128 for wide layers, 8 waves of 32x32 on 128x64
-        // for 64 output channels, 64x64 when the problem has few tiles
-        const long blocks128 = (long)((M + 127) / 128) * ((g->Cout + 127) / 128);
-        cfg = g->Cout > 64 ? (blocks128 >= 192 ? 1 : 3) : (g->Cout > 32 && (M + 127) / 128 >= 192 ? 2 : 3);
-    }
+    const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, M) : tile_cfg;
     const int bm = cfg == 3 ? 64 : 128;
     double* st_ptr = nullptr;
     if (rows_per_partial) {
@@ -1447,14 +1455,22 @@ extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_
         }
     }
     hipStream_t st = cg_s(stream);
-    const unsigned xl = (unsigned)(x_lo_elems * 2), xsp = (unsigned)x_span;
-    switch (cfg) {
-        case 0: return launch_x3<128, 128, 64, 64>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr, y_split, y_lo_elems);   // 4 waves
-        case 1: return launch_x3<128, 128, 64, 32>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr, y_split, y_lo_elems);   // 8 waves
-        case 2: return launch_x3<128, 64, 32, 32>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr, y_split, y_lo_elems);    // 8 waves
-        case 3: return launch_x3<64, 64, 32, 32>(b, xs, bias, y, xl, xsp, 1.0f / w_scale, st, st_ptr, y_split, y_lo_elems);     // 4 waves
-        default: return cg_set_error(CG_ERR_ARG, "cg_conv2d_fwd_x3: unknown tile configuration %d", cfg);
-    }
+    return launch_x3_cfg(cfg, b, 1, xs, bias, y, (unsigned)(x_lo_elems * 2), (unsigned)x_span, 1.0f / w_scale, x_scale_dev, st,
+                         st_ptr, y_split, y_lo_elems);
+}
+
+extern "C" int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, float* state,
+                                    cg_stream_t stream) {
+    CG_CHECK_ARG(x && out && state && n > 0 && lo_elems >= n, "cg_split_f16_dynamic: bad args");
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t st = cg_s(stream);
+    hipLaunchKernelGGL(amax_kernel, dim3(CG_AMAX_BLOCKS), dim3(256), 0, st, x, n, state);
+    CG_LAUNCH_CHECK("amax_kernel");
+    hipLaunchKernelGGL(split_f16_dyn_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)out, n, lo_elems, state);
+    CG_LAUNCH_CHECK("split_f16_dyn_kernel");
+    return CG_OK;
 }
 
 extern "C" int cg_conv2d_fwd_tile(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
@@ -1523,9 +1539,13 @@ extern "C" int cg_conv2d_wgrad_legacy(int on) {
 }
 
 static int launch_transpose(const float* w, float* out, int Cout, int T, int Cin, int ci0, int nci, const TransTable& tt,
-                            int nz, hipStream_t st) {
+                            int nz, hipStream_t st, bool split = false, float scale = 1.f, unsigned lo_elems = 0) {
     dim3 grid(cg_div_up(nci, 32), cg_div_up(Cout, 32), nz);
-    hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, st, w, out, Cout, T, Cin, ci0, nci, tt);
+    if (split)
+        hipLaunchKernelGGL(weight_transpose_kernel<true>, grid, dim3(256), 0, st, w, out, Cout, T, Cin, ci0, nci, tt, scale,
+                           lo_elems);
+    else
+        hipLaunchKernelGGL(weight_transpose_kernel<false>, grid, dim3(256), 0, st, w, out, Cout, T, Cin, ci0, nci, tt, 1.f, 0u);
     CG_LAUNCH_CHECK("weight_transpose_kernel");
     return CG_OK;
 }
@@ -1649,6 +1669,52 @@ extern "C" int cg_conv2d_dgrad(const cg_conv_geom* g, const float* dz, const flo
         if (rc) return rc;
     }
     return CG_OK;
+}
+
+// split-precision data-gradient: dz arrives as {hi, lo} fp16 planes with its device-side scale (cg_split_f16_dynamic);
+// the weights are re-laid-out AND split (scaled by CG_X3_WSCALE) by one launch into `ws`
+extern "C" int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, size_t dz_lo_elems,
+                                  const float* dz_scale_dev, const float* w, int ci0, int nci, float* dx, void* ws,
+                                  size_t ws_bytes, cg_stream_t stream) {
+    int rc = validate_geom(g, "cg_conv2d_dgrad_x3");
+    if (rc) return rc;
+    CG_CHECK_ARG(dz_split && w && dx && dz_scale_dev, "cg_conv2d_dgrad_x3: null pointer");
+    const int Cin = g->C1 + g->C2;
+    CG_CHECK_ARG(ci0 >= 0 && nci >= 1 && ci0 + nci <= Cin, "cg_conv2d_dgrad_x3: channel range outside %d", Cin);
+    CG_CHECK_ARG(g->Cout % BK == 0, "cg_conv2d_dgrad_x3: Cout %% 32 != 0");
+    if (!ws || ws_bytes < cg_conv2d_dgrad_workspace(g, nci))
+        return cg_set_error(CG_ERR_WORKSPACE, "cg_conv2d_dgrad_x3: workspace too small");
+    static thread_local DgradPlan p;
+    rc = plan_dgrad(g, nci, p);
+    if (rc) return rc;
+    CG_CHECK_ARG(p.ncls <= 4, "cg_conv2d_dgrad_x3: stride %d has more than 4 output classes", g->stride);
+    hipStream_t st = cg_s(stream);
+    TransTable tt;
+    memset(&tt, 0, sizeof(tt));
+    int nz = 0;
+    for (int c = 0; c < p.ncls; ++c)
+        for (int tc = 0; tc < p.cg[c].T; ++tc, ++nz) {
+            tt.src_tap[nz] = p.tap_src[c][tc];
+            tt.dst_base[nz] = (int32_t)p.w_off[c];
+            tt.dst_tc[nz] = tc;
+            tt.dst_T[nz] = p.cg[c].T;
+        }
+    const size_t wt_elems = p.ws_floats;          // one fp16 plane = as many elements as the fp32 layout had floats
+    const size_t dz_plane = (size_t)g->N * g->Ho * g->Wo * g->Cout * 2;
+    CG_CHECK_ARG(dz_lo_elems * 2 >= dz_plane && dz_lo_elems * 2 + dz_plane < (size_t)CG_OOB && 4 * wt_elems < (size_t)CG_OOB,
+                 "cg_conv2d_dgrad_x3: operand planes out of range");
+    rc = launch_transpose(w, (float*)ws, g->Cout, g->T, Cin, ci0, nci, tt, nz, st, true, CG_X3_WSCALE, (unsigned)wt_elems);
+    if (rc) return rc;
+    PipeBatch b;
+    long m_total = 0;
+    for (int c = 0; c < p.ncls; ++c) {
+        fill_class(b.c[c], &p.cg[c], (const float*)((const _Float16*)ws + p.w_off[c]));
+        b.c[c].w_bytes = (unsigned)(wt_elems * 2);                                                  // lo plane offset
+        b.c[c].pad_ = (int32_t)((wt_elems - p.w_off[c]) * 2 + wt_elems * 2);                       // span from this class's base
+        m_total += b.c[c].M;
+    }
+    return launch_x3_cfg(pick_x3_cfg(nci, m_total), b, p.ncls, dz_split, nullptr, dx, (unsigned)(dz_lo_elems * 2),
+                         (unsigned)(dz_lo_elems * 2 + dz_plane), 1.0f / CG_X3_WSCALE, dz_scale_dev, st, nullptr, nullptr, 0);
 }
 
 extern "C" int cg_debug_fetch(long long* host, int nwords) {

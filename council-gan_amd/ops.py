@@ -129,8 +129,8 @@ class _Conv2d(torch.autograd.Function):
                 ysp = SplitTensor(torch.empty(2 * y.numel(), dtype=torch.float16, device=y.device), y.shape)
                 out_split.append(ysp)
             check(lib.cg_conv2d_fwd_x3(byref(g), xsplit.hi_ptr(), xsplit.lo, wsplit.hi_ptr(), wsplit.lo, float(wsplit.scale),
-                                       ptr(bias), ptr(y), ysp.hi_ptr() if ysp else None, ysp.lo if ysp else 0, ptr(sws), sbytes,
-                                       rp, -1, stream()), "cg_conv2d_fwd_x3")
+                                       xsplit.scale_ptr(), ptr(bias), ptr(y), ysp.hi_ptr() if ysp else None,
+                                       ysp.lo if ysp else 0, ptr(sws), sbytes, rp, -1, stream()), "cg_conv2d_fwd_x3")
             if stats is not None and rows.value:
                 stats.append((sws, rows.value))
         elif stats is not None and act == 0:
@@ -177,15 +177,23 @@ class _Conv2d(torch.autograd.Function):
                 dw, db = dw_t, db_t
             check(lib.cg_conv2d_wgrad(byref(g), ptr(x), ptr(x2), ptr(dz), ptr(dw_t), ptr(db_t), acc, ptr(ws),
                                       ws.numel(), stream()), "cg_conv2d_wgrad")
+        # data gradients: split-precision kernel when the layer qualifies (dz gets a device-side power-of-two scale)
+        dgrad = conv_dgrad
+        if X3_BACKWARD and g.Cout % 32 == 0 and g.stride <= 2 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            dz_in, dgrad = split_f16_dynamic(dz), conv_dgrad_x3
+        else:
+            dz_in = dz
         if ctx.needs_input_grad[0]:
-            dx = conv_dgrad(g, dz, w, 0, x.shape[1])
+            dx = dgrad(g, dz_in, w, 0, x.shape[1])
         dx2 = None
         if x2 is not None and ctx.needs_input_grad[1]:
-            dx2 = conv_dgrad(g, dz, w, x.shape[1], x2.shape[1])
+            dx2 = dgrad(g, dz_in, w, x.shape[1], x2.shape[1])
         return dx, dx2, dw, db, None, None, None, None, None, None, None, None, None, None
 
 
-X3_FORWARD = True     # module switch (Council_Trainer sets it from the config): split-precision forward convolutions
+X3_FORWARD = True     # module switches (Council_Trainer sets them from the config): split-precision forward convolutions,
+X3_BACKWARD = True    # split-precision data gradients, dynamic (device-scaled) splitting of un-normalised conv inputs
+X3_DYNAMIC_INPUT = True
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=False, stats=None, wmgr=None,
@@ -198,15 +206,19 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=
     the output gets one for the next convolution."""
     xsplit = wsplit = out_split = None
     if X3_FORWARD and wmgr is not None and x2 is None and x3_eligible(x.shape[1], 0) and weight.dim() == 4:
-        # only inputs whose producer emitted the split form qualify: those are instance-normalised (or one fused
-        # conv+ReLU away from it), i.e. O(1) activations inside fp16's accurate range -- an arbitrary-scale tensor
-        # would need a per-tensor power-of-two scale first (DESIGN.md section 4.5)
+        # inputs whose producer emitted the split form are instance-normalised (or one fused conv+ReLU away from it),
+        # i.e. O(1) activations inside fp16's accurate range, and travel unscaled; any other input is split here
+        # with a per-tensor power-of-two scale chosen on the device (DESIGN.md section 4.5)
         xsplit = getattr(x, "_cg_split", None)
-        wsplit = wmgr.get(weight) if xsplit is not None else None
+        wsplit = wmgr.get(weight) if (xsplit is not None or X3_DYNAMIC_INPUT) else None
         if wsplit is None:
             xsplit = None
-        elif want_split and stats is None:        # with a norm next, the norm's apply pass emits the split form
-            out_split = []
+        else:
+            if xsplit is None:       # arbitrary-scale input (discriminator activations): per-tensor scale on the device
+                with torch.no_grad():
+                    xsplit = split_f16_dynamic(x.detach())
+            if want_split and stats is None and xsplit.state is None:
+                out_split = []       # O(1) chain (norm -> conv+ReLU -> conv): the epilogue emits the next operand
     y = _Conv2d.apply(x, x2, weight, bias, getattr(weight, "_cg_grad", None),
                       getattr(bias, "_cg_grad", None) if bias is not None else None,
                       int(stride), int(pad), ACT[act], bool(upsample), stats, xsplit, wsplit, out_split)
@@ -390,8 +402,9 @@ class SplitTensor:
     `buf` is a flat fp16 tensor; the hi plane starts at element `off`, the lo plane `lo` elements later; `scale` is
     the power of two s the values were multiplied by (weights: hip.X3_WSCALE)."""
 
-    def __init__(self, buf, shape, off=0, lo=None, scale=1.0):
+    def __init__(self, buf, shape, off=0, lo=None, scale=1.0, state=None):
         self.buf, self.shape, self.off, self.scale = buf, tuple(shape), off, scale
+        self.state = state      # device float[2] of a dynamically scaled tensor: [1] = the power-of-two scale in use
         n = 1
         for d in shape:
             n *= d
@@ -400,6 +413,9 @@ class SplitTensor:
 
     def hi_ptr(self):
         return c_void_p(self.buf.data_ptr() + 2 * self.off)
+
+    def scale_ptr(self):
+        return None if self.state is None else c_void_p(self.state.data_ptr() + 4)
 
 
 class SplitWeights:
@@ -447,6 +463,33 @@ def split_f16(x, scale=1.0):
     return SplitTensor(buf, x.shape, scale=scale)
 
 
+def split_f16_dynamic(x):
+    """fp32 tensor of ARBITRARY magnitude (a gradient, an un-normalised activation) -> SplitTensor whose planes hold
+    scale*x, scale = the power of two that puts max|x| into [32, 64), chosen on the device (no host sync)."""
+    x = nhwc(x) if x.dim() == 4 else x.contiguous()
+    buf = torch.empty(2 * x.numel(), dtype=torch.float16, device=x.device)
+    state = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=x.device)
+    check(_lib().cg_split_f16_dynamic(ptr(x), ptr(buf), x.numel(), x.numel(), ptr(state), stream()), "cg_split_f16_dynamic")
+    return SplitTensor(buf, x.shape, state=state)
+
+
+def conv_dgrad_x3(g, dz, w, ci0, nci):
+    """conv_dgrad on the split-precision kernel: dz is split with its device-side scale, the weights are re-laid-out
+    and split by the library; needs Cout % 32 == 0."""
+    lib = _lib()
+    N, H, W, up = g.N, g.H, g.W, g.up
+    dzs = dz if isinstance(dz, SplitTensor) else split_f16_dynamic(dz)
+    dxl = torch.empty((N, nci, H << up, W << up), dtype=torch.float32, device=dzs.buf.device, memory_format=CL)
+    ws = workspace(lib.cg_conv2d_dgrad_workspace(byref(g), nci))
+    check(lib.cg_conv2d_dgrad_x3(byref(g), dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), ptr(w), ci0, nci, ptr(dxl), ptr(ws), ws.numel(),
+                                 stream()), "cg_conv2d_dgrad_x3")
+    if not up:
+        return dxl
+    dx = empty_nhwc(N, nci, H, W, dxl)
+    check(lib.cg_upsample2x_bwd(ptr(dxl), ptr(dx), N, H, W, nci, stream()), "cg_upsample2x_bwd")
+    return dx
+
+
 def conv2d_x3(xs, wsplit, Cout, KH, KW, bias=None, stride=1, pad=0, act="none", upsample=False, stats=None):
     """act(conv2d(zero_pad(x), W) + bias) on the fp16 MFMA with every product expanded as ah*bh + ah*bl + al*bh.
     xs: SplitTensor activation; wsplit: SplitTensor over the physical [Cout][KH][KW][Cin] weight.  No autograd."""
@@ -463,9 +506,9 @@ def conv2d_x3(xs, wsplit, Cout, KH, KW, bias=None, stride=1, pad=0, act="none", 
         sws = workspace(((m + 63) // 64) * Cout * 16, slot=1)
         sbytes, rp = sws.numel(), byref(rows)
     if xs.scale != 1.0:
-        raise hip.HipError("conv2d_x3: activations must be split unscaled")
-    check(lib.cg_conv2d_fwd_x3(byref(g), xs.hi_ptr(), xs.lo, wsplit.hi_ptr(), wsplit.lo, float(wsplit.scale), ptr(bias), ptr(y),
-                               None, 0, ptr(sws), sbytes, rp, -1, stream()), "cg_conv2d_fwd_x3")
+        raise hip.HipError("conv2d_x3: activations carry a static scale of 1 or a device-side one")
+    check(lib.cg_conv2d_fwd_x3(byref(g), xs.hi_ptr(), xs.lo, wsplit.hi_ptr(), wsplit.lo, float(wsplit.scale), xs.scale_ptr(),
+                               ptr(bias), ptr(y), None, 0, ptr(sws), sbytes, rp, -1, stream()), "cg_conv2d_fwd_x3")
     if stats is not None and rows.value:
         stats.append((sws, rows.value))
     return y

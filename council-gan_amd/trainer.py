@@ -220,10 +220,11 @@ class Council_Trainer(nn.Module):
         # split-precision forward convolutions in the GENERATORS (instance-normalised activations: inside fp16's
         # accurate range by construction; the un-normalised discriminators stay on fp32 MFMA): one lazily refreshed
         # {hi, lo} fp16 copy of the generator optimizer's weights
-        ops.X3_FORWARD = self._split_fwd
+        ops.X3_FORWARD = ops.X3_BACKWARD = ops.X3_DYNAMIC_INPUT = self._split_fwd
         if self._split_fwd:
             for i in self.shard.local:
-                for kind, opt in (('gen', self.gen_opt_s[i]),):
+                for kind, opt in (('gen', self.gen_opt_s[i]), ('dis', self.dis_opt_s[i])) + \
+                        ((('disc', self.dis_council_opt_s[i]),) if self.do_dis_council else ()):
                     mgr = ops.SplitWeights(opt)
                     for d in self._dirs:
                         net = self._nets(kind, d)[i]

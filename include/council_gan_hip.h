@@ -88,8 +88,19 @@ int cg_conv2d_fwd_stats(const cg_conv_geom* g, const float* x1, const float* x2,
 #define CG_X3_WSCALE 1024.0f
 int cg_split_f16(const float* x, void* out, size_t n, size_t lo_elems, float scale, cg_stream_t stream);
 int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* x_hi, size_t x_lo_elems, const void* w_hi, size_t w_lo_elems,
-                     float w_scale, const float* bias, float* y, void* y_split, size_t y_lo_elems, double* stats,
-                     size_t stats_bytes, int* rows_per_partial, int tile_cfg, cg_stream_t stream);
+                     float w_scale, const float* x_scale_dev, const float* bias, float* y, void* y_split,
+                     size_t y_lo_elems, double* stats, size_t stats_bytes, int* rows_per_partial, int tile_cfg,
+                     cg_stream_t stream);
+/* Tensors of arbitrary magnitude (gradients, un-normalised activations) are split with a per-tensor power-of-two scale
+ * chosen ON THE DEVICE: state[0] <- max|x|, state[1] <- scale = 2^(5 - floor(log2 max|x|)) (scaled peak in [32, 64));
+ * state[2 .. CG_SPLIT_STATE_FLOATS) is scratch (per-block maxima: no atomics, nothing to zero).  Planes hold scale*x;
+ * consumers take `state + 1` as x_scale_dev / dz_scale_dev and undo the scale in their epilogue.  No host sync. */
+#define CG_SPLIT_STATE_FLOATS 258
+int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, float* state, cg_stream_t stream);
+/* split-precision data gradient (cg_conv2d_dgrad with dz pre-split by cg_split_f16_dynamic; needs Cout % 32 == 0);
+ * ws: cg_conv2d_dgrad_workspace(g, nci) bytes (holds the re-laid-out, split weights) */
+int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, size_t dz_lo_elems, const float* dz_scale_dev,
+                       const float* w, int ci0, int nci, float* dx, void* ws, size_t ws_bytes, cg_stream_t stream);
 /* y_split (optional): the output ALSO in split form (hi plane, lo plane y_lo_elems halves later) for a convolution
  * that consumes it next */
 /* instance norm / AdaIN apply that writes the split form of its output (and / or fp32): the producer side of

@@ -24,8 +24,8 @@ def split(lib, t, scale=1.0):
 
 
 def run_x3(lib, g, xs, ws, b, y, cfg):
-    hip.check(lib.cg_conv2d_fwd_x3(byref(g), hip.ptr(xs), xs.numel() // 2, hip.ptr(ws), ws.numel() // 2, hip.X3_WSCALE, hip.ptr(b),
-                                   hip.ptr(y), None, 0, None, 0, None, cfg, hip.stream()), "x3")
+    hip.check(lib.cg_conv2d_fwd_x3(byref(g), hip.ptr(xs), xs.numel() // 2, hip.ptr(ws), ws.numel() // 2, hip.X3_WSCALE, None,
+                                   hip.ptr(b), hip.ptr(y), None, 0, None, 0, None, cfg, hip.stream()), "x3")
 
 
 def main():
