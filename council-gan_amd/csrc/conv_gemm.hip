@@ -1118,8 +1118,8 @@ struct ProfScope {
                      bn, g->N, g->H, g->W, g->C1 + g->C2, g->Cout, g->T, g->stride, g->up, g->Ho, g->Wo, ncls);
         rec.slot = family * 16 + tile_id(bm, bn) * 2 + (fast ? 1 : 0);
         rec.flops = flops;
-        static const char* const fam[5] = {"conv_fwd_kernel", "conv_wgrad_kernel", "conv_fwd_pipe_kernel",
-                                           "conv_wgrad_pipe_kernel", "conv_fwd_x3_kernel"};
+        static const char* const fam[6] = {"conv_fwd_kernel", "conv_wgrad_kernel", "conv_fwd_pipe_kernel",
+                                           "conv_wgrad_pipe_kernel", "conv_fwd_x3_kernel", "conv_wgrad_x3_kernel"};
         snprintf(prof_names[rec.slot], sizeof(prof_names[0]), "%s<%d,%d,%s>", fam[family], bm, bn, fast ? "fast" : "generic");
         (void)hipEventCreate(&rec.e0);
         (void)hipEventCreate(&rec.e1);
@@ -1517,6 +1517,73 @@ extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const flo
     else return cg_set_error(CG_ERR_ARG, "cg_conv2d_wgrad: no tile for %dx%d", p.bm, p.bn);
 #undef WG
 #undef WGP
+    if (rc) return rc;
+    const size_t nw = (size_t)g->Cout * K;
+    const size_t n = nw + (want_bias ? g->Cout : 0);
+    if (p.splits >= 128)
+        hipLaunchKernelGGL(splitk_reduce_kernel<64>, dim3(cg_div_up(n * 64, 256)), dim3(256), 0, st, (const float*)part, dw,
+                           dbias, nw, g->Cout, p.splits, accumulate);
+    else if (p.splits >= 24)
+        hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(cg_div_up(n * 8, 256)), dim3(256), 0, st, (const float*)part, dw, dbias,
+                           nw, g->Cout, p.splits, accumulate);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cg_div_up(n, 256)), dim3(256), 0, st, (const float*)part, dw, dbias,
+                           nw, g->Cout, p.splits, accumulate);
+    CG_LAUNCH_CHECK("splitk_reduce_kernel");
+    return CG_OK;
+}
+
+// split-precision weight gradient (conv_x3.inc): x and dz arrive as {hi, lo} fp16 planes with their power-of-two
+// scales (device-side pointers, NULL = 1); same planning, partial layout and deterministic reduce as cg_conv2d_wgrad
+namespace {
+template <int BM, int BN, int WM, int WN>
+int launch_wgrad_x3(const cg_conv_geom* g, const WgradPlan& p, const void* xs, size_t x_lo, const float* x_scale,
+                    const void* dzs, size_t dz_lo, const float* dz_scale, float* out, int M, int K, int want_bias,
+                    hipStream_t st) {
+    dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits), block((BM / WM) * (BN / WN) * 64);
+    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)M * g->Cout * 2;
+    ProfScope prof(5, BM, BN, true, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
+    hipLaunchKernelGGL((conv_wgrad_x3_kernel<BM, BN, WM, WN>), grid, block, 0, st, *g, xs, (unsigned)(x_lo * 2),
+                       (unsigned)(x_lo * 2 + x_plane), x_scale, dzs, (unsigned)(dz_lo * 2), (unsigned)(dz_lo * 2 + dz_plane),
+                       dz_scale, out, M, K, p.tiles_n, p.slices_per_split, want_bias, ilog2_exact(g->Ho * g->Wo),
+                       ilog2_exact(g->Wo));
+    CG_LAUNCH_CHECK("conv_wgrad_x3_kernel");
+    return CG_OK;
+}
+}  // namespace
+
+extern "C" int cg_conv2d_wgrad_x3_ok(const cg_conv_geom* g) {
+    if (!g || g->T < 1 || g->T > CG_MAX_TAPS) return 0;
+    const int M = g->N * g->Ho * g->Wo;
+    WgradPlan p = plan_wgrad(g);
+    return wgrad_pipe_ok(g, p, M) && (g->Cout & 7) == 0 && (g->C1 & 7) == 0;
+}
+
+extern "C" int cg_conv2d_wgrad_x3(const cg_conv_geom* g, const void* xs, size_t x_lo_elems, const float* x_scale_dev,
+                                  const void* dzs, size_t dz_lo_elems, const float* dz_scale_dev, float* dw, float* dbias,
+                                  int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
+    int rc = validate_geom(g, "cg_conv2d_wgrad_x3");
+    if (rc) return rc;
+    CG_CHECK_ARG(xs && dzs && dw, "cg_conv2d_wgrad_x3: null pointer");
+    CG_CHECK_ARG(cg_conv2d_wgrad_x3_ok(g), "cg_conv2d_wgrad_x3: layer does not qualify (see cg_conv2d_wgrad_x3_ok)");
+    const size_t need = cg_conv2d_wgrad_workspace(g);
+    if (!ws || ws_bytes < need) return cg_set_error(CG_ERR_WORKSPACE, "cg_conv2d_wgrad_x3: workspace %zu < %zu", ws_bytes, need);
+    const int K = g->T * g->C1;
+    const int M = g->N * g->Ho * g->Wo;
+    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)M * g->Cout * 2;
+    CG_CHECK_ARG(x_lo_elems * 2 >= x_plane && dz_lo_elems * 2 >= dz_plane && x_lo_elems * 2 + x_plane < (size_t)CG_OOB &&
+                     dz_lo_elems * 2 + dz_plane < (size_t)CG_OOB, "cg_conv2d_wgrad_x3: operand planes out of range");
+    hipStream_t st = cg_s(stream);
+    WgradPlan p = plan_wgrad(g);
+    float* part = (float*)ws;
+    const int want_bias = dbias != nullptr;
+#define WGX(BM_, BN_, WM_, WN_) \
+    rc = launch_wgrad_x3<BM_, BN_, WM_, WN_>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st)
+    if (p.bm == 128 && p.bn == 128) WGX(128, 128, 64, 32);   // 8 waves
+    else if (p.bm == 128 && p.bn == 64) WGX(128, 64, 64, 32);
+    else if (p.bm == 64 && p.bn == 64) WGX(64, 64, 32, 32);
+    else WGX(64, 128, 32, 64);
+#undef WGX
     if (rc) return rc;
     const size_t nw = (size_t)g->Cout * K;
     const size_t n = nw + (want_bias ? g->Cout : 0);

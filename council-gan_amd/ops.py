@@ -145,6 +145,7 @@ class _Conv2d(torch.autograd.Function):
         else:
             check(lib.cg_conv2d_fwd(byref(g), ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), stream()), "cg_conv2d_fwd")
         ctx.save_for_backward(x, x2, w, y if act else None)
+        ctx.xsplit = xsplit if (xsplit is not None and wsplit is not None) else None     # reused by the x3 weight gradient
         ctx.g, ctx.meta = g, (KH, KW, stride, pad, act, int(up), bias is not None)
         ctx.wgrad_buf, ctx.bgrad_buf = wgrad_buf, bgrad_buf
         return y
@@ -162,7 +163,13 @@ class _Conv2d(torch.autograd.Function):
         else:
             dz = dy
         dx = dw = db = None
-        if ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3]):
+        # split-precision backward: dz gets a device-side power-of-two scale once, for both gradients
+        need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
+        need_dw = ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3])
+        x3_dgrad = X3_BACKWARD and need_dx and g.Cout % 32 == 0 and g.stride <= 2
+        x3_wgrad = X3_BACKWARD and need_dw and ctx.xsplit is not None and bool(lib.cg_conv2d_wgrad_x3_ok(byref(g)))
+        dzs = split_f16_dynamic(dz) if (x3_dgrad or x3_wgrad) else None
+        if need_dw:
             ws = workspace(lib.cg_conv2d_wgrad_workspace(byref(g)))
             if ctx.wgrad_buf is not None:
                 # accumulate straight into the optimizer's flat gradient buffer (optim.py)
@@ -175,14 +182,15 @@ class _Conv2d(torch.autograd.Function):
                 dw_t, acc = torch.empty_like(w), 0
                 db_t = torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if has_bias else None
                 dw, db = dw_t, db_t
-            check(lib.cg_conv2d_wgrad(byref(g), ptr(x), ptr(x2), ptr(dz), ptr(dw_t), ptr(db_t), acc, ptr(ws),
-                                      ws.numel(), stream()), "cg_conv2d_wgrad")
+            if x3_wgrad:
+                xs = ctx.xsplit
+                check(lib.cg_conv2d_wgrad_x3(byref(g), xs.hi_ptr(), xs.lo, xs.scale_ptr(), dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(),
+                                             ptr(dw_t), ptr(db_t), acc, ptr(ws), ws.numel(), stream()), "cg_conv2d_wgrad_x3")
+            else:
+                check(lib.cg_conv2d_wgrad(byref(g), ptr(x), ptr(x2), ptr(dz), ptr(dw_t), ptr(db_t), acc, ptr(ws),
+                                          ws.numel(), stream()), "cg_conv2d_wgrad")
         # data gradients: split-precision kernel when the layer qualifies (dz gets a device-side power-of-two scale)
-        dgrad = conv_dgrad
-        if X3_BACKWARD and g.Cout % 32 == 0 and g.stride <= 2 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
-            dz_in, dgrad = split_f16_dynamic(dz), conv_dgrad_x3
-        else:
-            dz_in = dz
+        dgrad, dz_in = (conv_dgrad_x3, dzs) if x3_dgrad else (conv_dgrad, dz)
         if ctx.needs_input_grad[0]:
             dx = dgrad(g, dz_in, w, 0, x.shape[1])
         dx2 = None

@@ -101,6 +101,13 @@ int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, f
  * ws: cg_conv2d_dgrad_workspace(g, nci) bytes (holds the re-laid-out, split weights) */
 int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, size_t dz_lo_elems, const float* dz_scale_dev,
                        const float* w, int ci0, int nci, float* dx, void* ws, size_t ws_bytes, cg_stream_t stream);
+/* split-precision weight gradient: cg_conv2d_wgrad with x and dz given as {hi, lo} fp16 planes (+ device-side scales,
+ * NULL = 1).  cg_conv2d_wgrad_x3_ok(g) != 0 iff the layer qualifies (one source, every k-tile inside one tap,
+ * channel counts multiples of 8, power-of-two output plane); workspace as cg_conv2d_wgrad_workspace(g). */
+int cg_conv2d_wgrad_x3_ok(const cg_conv_geom* g);
+int cg_conv2d_wgrad_x3(const cg_conv_geom* g, const void* x_split, size_t x_lo_elems, const float* x_scale_dev,
+                       const void* dz_split, size_t dz_lo_elems, const float* dz_scale_dev, float* dw, float* dbias,
+                       int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream);
 /* y_split (optional): the output ALSO in split form (hi plane, lo plane y_lo_elems halves later) for a convolution
  * that consumes it next */
 /* instance norm / AdaIN apply that writes the split form of its output (and / or fp32): the producer side of
@@ -228,7 +235,7 @@ int cg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
  * HIP events recorded on the launch stream.  cg_prof_collect() synchronises them and returns, per
  * kernel slot (slot = kernel family * 16 + tile shape * 2 + fast-path flag; see cg_prof_slot_name),
  * launch count, total milliseconds and total algorithmic FLOPs (2*M*N*K of each launch). */
-#define CG_PROF_SLOTS 80
+#define CG_PROF_SLOTS 96
 int cg_prof_enable(int on);
 int cg_prof_collect(int64_t* counts, double* ms, double* flops);
 const char* cg_prof_slot_name(int slot);
