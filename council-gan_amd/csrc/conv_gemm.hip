@@ -1459,16 +1459,21 @@ extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_
                          st_ptr, y_split, y_lo_elems);
 }
 
-extern "C" int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, float* state,
+extern "C" int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, float* state, int nslots,
                                     cg_stream_t stream) {
-    CG_CHECK_ARG(x && out && state && n > 0 && lo_elems >= n, "cg_split_f16_dynamic: bad args");
+    CG_CHECK_ARG(x && out && state && n > 0 && lo_elems >= n && nslots >= 0 && nslots <= CG_AMAX_MAX_SLOTS,
+                 "cg_split_f16_dynamic: bad args");
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipStream_t st = cg_s(stream);
-    hipLaunchKernelGGL(amax_kernel, dim3(CG_AMAX_BLOCKS), dim3(256), 0, st, x, n, state);
-    CG_LAUNCH_CHECK("amax_kernel");
-    hipLaunchKernelGGL(split_f16_dyn_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)out, n, lo_elems, state);
+    if (nslots == 0) {      // nobody measured the tensor yet: one reduction pass; otherwise the producer filled the slots
+        hipLaunchKernelGGL(amax_kernel, dim3(CG_AMAX_BLOCKS), dim3(256), 0, st, x, n, state);
+        CG_LAUNCH_CHECK("amax_kernel");
+        nslots = CG_AMAX_BLOCKS;
+    }
+    hipLaunchKernelGGL(split_f16_dyn_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)out, n, lo_elems, state,
+                       nslots);
     CG_LAUNCH_CHECK("split_f16_dyn_kernel");
     return CG_OK;
 }
@@ -1735,6 +1740,21 @@ extern "C" int cg_conv2d_dgrad(const cg_conv_geom* g, const float* dz, const flo
         rc = cg_conv2d_fwd(&p.cg[c], dz, nullptr, wt + p.w_off[c], nullptr, dx, stream);
         if (rc) return rc;
     }
+    return CG_OK;
+}
+
+extern "C" int cg_act_bwd_split(const float* dy, const float* y, size_t n, int act, void* out, size_t lo_elems,
+                                float* state, float* dz, cg_stream_t stream) {
+    CG_CHECK_ARG(dy && y && out && state && n > 0 && lo_elems >= n, "cg_act_bwd_split: bad args");
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t st = cg_s(stream);
+    hipLaunchKernelGGL(act_bwd_amax_kernel, dim3(CG_AMAX_BLOCKS), dim3(256), 0, st, dy, y, dz, n, act, state);
+    CG_LAUNCH_CHECK("act_bwd_amax_kernel");
+    hipLaunchKernelGGL(act_bwd_split_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, (_Float16*)out, n, lo_elems, act,
+                       state, CG_AMAX_BLOCKS);
+    CG_LAUNCH_CHECK("act_bwd_split_kernel");
     return CG_OK;
 }
 

@@ -362,7 +362,9 @@ __global__ __launch_bounds__(256) void in_bwd_apply_q(const float* __restrict__ 
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ s12, float* __restrict__ dx, int HW, int C,
-                                                      int act, int gs) {
+                                                      int act, int gs, float* __restrict__ amax_state) {
+    __shared__ float red[4];
+    float amax = 0.f;
     const int n = blockIdx.y;
     const int nq = HW * (C >> 2);
     const int step = gridDim.x * 256;
@@ -386,8 +388,17 @@ __global__ __launch_bounds__(256) void in_bwd_apply_q(const float* __restrict__ 
             const float xh = (xs[k] - q.m[k]) * q.r[k];
             const float dz = in_dz(ds[k], xh, q.g[k], q.b[k], act);
             o[k] = q.r[k] * q.g[k] * (dz - s1[k] - xh * s2[k]);
+            amax = fmaxf(amax, fabsf(o[k]));
         }
         st4(dx + 4 * (size_t)i, make_float4(o[0], o[1], o[2], o[3]));
+    }
+    if (amax_state) {   // per-block max |dx| for the split-precision consumers (cg_split_f16_dynamic with nslots = grid size)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            amax_state[2 + blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     }
 }
 
@@ -620,7 +631,8 @@ extern "C" int cg_instnorm_apply_split(const float* x, const float* mean, const 
 extern "C" int cg_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                const float* gamma, const float* beta, int gstride, float* dx, float* dgamma,
                                float* dbeta, int N, int HW, int C, int act, void* ws, size_t ws_bytes,
-                               cg_stream_t stream) {
+                               float* amax_state, int* amax_nslots, cg_stream_t stream) {
+    if (amax_nslots) *amax_nslots = 0;
     CG_CHECK_ARG(dy && x && mean && rstd && dx && N > 0 && HW > 0 && C > 0, "cg_instnorm_bwd: bad args");
     CG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "cg_instnorm_bwd: gamma and beta go together");
     if (!ws || ws_bytes < cg_instnorm_workspace(N, HW, C))
@@ -640,9 +652,17 @@ extern "C" int cg_instnorm_bwd(const float* dy, const float* x, const float* mea
                        s12, dgamma, dbeta, N * C, S, HW, C, gstride);
     CG_LAUNCH_CHECK("in_bwd_final");
     const size_t total = (size_t)N * HW * C;
-    if (quad)
-        hipLaunchKernelGGL(in_bwd_apply_q, dim3(quad_grid(HW, C, N), N), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma,
-                           beta, (const float*)s12, dx, HW, C, act, gstride);
+    if (quad) {
+        unsigned gx = quad_grid(HW, C, N);
+        float* st = nullptr;
+        if (amax_state && amax_nslots && N <= 1024) {
+            if (gx * (unsigned)N > 1024u) gx = 1024u / (unsigned)N;
+            st = amax_state;
+            *amax_nslots = (int)(gx * (unsigned)N);
+        }
+        hipLaunchKernelGGL(in_bwd_apply_q, dim3(gx, N), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma, beta,
+                           (const float*)s12, dx, HW, C, act, gstride, st);
+    }
     else
         hipLaunchKernelGGL(in_bwd_apply, dim3(ew_grid(total)), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma, beta,
                            (const float*)s12, dx, total, HW, C, act, gstride);

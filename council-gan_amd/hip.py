@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcouncilgan_hip.so")
 ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "tanh": 3}
 MAX_TAPS = 64
 X3_WSCALE = 1024.0      # CG_X3_WSCALE: power-of-two pre-scale of split-precision weights
-SPLIT_STATE_FLOATS = 258  # CG_SPLIT_STATE_FLOATS
+SPLIT_STATE_FLOATS = 1026  # CG_SPLIT_STATE_FLOATS
 
 
 class ConvGeom(ctypes.Structure):
@@ -43,7 +43,8 @@ _SIGS = {
                                  POINTER(c_int), c_int, _P]),
     "cg_conv2d_wgrad_x3_ok": (c_int, [POINTER(ConvGeom)]),
     "cg_conv2d_wgrad_x3": (c_int, [POINTER(ConvGeom), _P, c_size_t, _P, _P, c_size_t, _P, _P, _P, c_int, _P, c_size_t, _P]),
-    "cg_split_f16_dynamic": (c_int, [_P, _P, c_size_t, c_size_t, _P, _P]),
+    "cg_split_f16_dynamic": (c_int, [_P, _P, c_size_t, c_size_t, _P, c_int, _P]),
+    "cg_act_bwd_split": (c_int, [_P, _P, c_size_t, c_int, _P, c_size_t, _P, _P, _P]),
     "cg_conv2d_dgrad_x3": (c_int, [POINTER(ConvGeom), _P, c_size_t, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "cg_instnorm_apply_split": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, _P]),
     "cg_conv2d_fwd_tile": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P]),
@@ -58,7 +59,8 @@ _SIGS = {
     "cg_instnorm_workspace": (c_size_t, [c_int, c_int, c_int]),
     "cg_instnorm_stats": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
     "cg_instnorm_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "cg_instnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "cg_instnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P,
+                                POINTER(c_int), _P]),
     "cg_layernorm_workspace": (c_size_t, [c_int, c_int, c_int]),
     "cg_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
     "cg_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),

@@ -156,19 +156,26 @@ class _Conv2d(torch.autograd.Function):
         x, x2, w, y = ctx.saved_tensors
         KH, KW, stride, pad, act, up, has_bias = ctx.meta
         g = ctx.g
+        amax = getattr(dy, "_cg_amax", None)
         dy = nhwc(dy)
-        if act:
-            dz = torch.empty_like(dy)
-            check(lib.cg_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), act, stream()), "cg_act_bwd")
-        else:
-            dz = dy
         dx = dw = db = None
         # split-precision backward: dz gets a device-side power-of-two scale once, for both gradients
         need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
         need_dw = ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3])
         x3_dgrad = X3_BACKWARD and need_dx and g.Cout % 32 == 0 and g.stride <= 2
         x3_wgrad = X3_BACKWARD and need_dw and ctx.xsplit is not None and bool(lib.cg_conv2d_wgrad_x3_ok(byref(g)))
-        dzs = split_f16_dynamic(dz) if (x3_dgrad or x3_wgrad) else None
+        fp32_needed = (need_dx and not x3_dgrad) or (need_dw and not x3_wgrad)
+        dzs = None
+        if act:
+            if x3_dgrad or x3_wgrad:
+                dz, dzs = act_bwd_split(dy, y, act, fp32_needed)        # no fp32 round trip of dz when nobody reads it
+            else:
+                dz = torch.empty_like(dy)
+                check(lib.cg_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), act, stream()), "cg_act_bwd")
+        else:
+            dz = dy
+            if x3_dgrad or x3_wgrad:
+                dzs = split_f16_dynamic(dz, amax)
         if need_dw:
             ws = workspace(lib.cg_conv2d_wgrad_workspace(byref(g)))
             if ctx.wgrad_buf is not None:
@@ -310,8 +317,13 @@ class _InstNormAct(torch.autograd.Function):
         else:
             gp = bp = dgp = dbp = None
             gs = C
+        state, nslots = None, ctypes.c_int(0)
+        if X3_BACKWARD:
+            state = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=x.device)
         check(lib.cg_instnorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(dx), dgp, dbp, N, HW, C, act,
-                                  ptr(ws), ws.numel(), stream()), "cg_instnorm_bwd")
+                                  ptr(ws), ws.numel(), ptr(state), byref(nslots), stream()), "cg_instnorm_bwd")
+        if nslots.value:
+            dx._cg_amax = (state, nslots.value)     # the conv before this norm splits dx without measuring it again
         return dx, dparams, None, None, (dy if has_res else None), None, None, None, None
 
 
@@ -471,14 +483,28 @@ def split_f16(x, scale=1.0):
     return SplitTensor(buf, x.shape, scale=scale)
 
 
-def split_f16_dynamic(x):
+def split_f16_dynamic(x, amax=None):
     """fp32 tensor of ARBITRARY magnitude (a gradient, an un-normalised activation) -> SplitTensor whose planes hold
     scale*x, scale = the power of two that puts max|x| into [32, 64), chosen on the device (no host sync)."""
     x = nhwc(x) if x.dim() == 4 else x.contiguous()
     buf = torch.empty(2 * x.numel(), dtype=torch.float16, device=x.device)
-    state = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=x.device)
-    check(_lib().cg_split_f16_dynamic(ptr(x), ptr(buf), x.numel(), x.numel(), ptr(state), stream()), "cg_split_f16_dynamic")
+    if amax is not None:            # (state, nslots) left behind by the kernel that produced x
+        state, nslots = amax
+    else:
+        state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=x.device), 0
+    check(_lib().cg_split_f16_dynamic(ptr(x), ptr(buf), x.numel(), x.numel(), ptr(state), nslots, stream()),
+          "cg_split_f16_dynamic")
     return SplitTensor(buf, x.shape, state=state)
+
+
+def act_bwd_split(dy, y, act, want_fp32):
+    """dz = dy * act'(y) as a dynamically scaled SplitTensor (+ the fp32 tensor when a non-split kernel still needs it)."""
+    buf = torch.empty(2 * dy.numel(), dtype=torch.float16, device=dy.device)
+    state = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=dy.device)
+    dz = torch.empty_like(dy) if want_fp32 else None
+    check(_lib().cg_act_bwd_split(ptr(dy), ptr(y), dy.numel(), act, ptr(buf), dy.numel(), ptr(state), ptr(dz), stream()),
+          "cg_act_bwd_split")
+    return dz, SplitTensor(buf, dy.shape, state=state)
 
 
 def conv_dgrad_x3(g, dz, w, ci0, nci):

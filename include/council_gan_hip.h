@@ -95,8 +95,14 @@ int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* x_hi, size_t x_lo_elems,
  * chosen ON THE DEVICE: state[0] <- max|x|, state[1] <- scale = 2^(5 - floor(log2 max|x|)) (scaled peak in [32, 64));
  * state[2 .. CG_SPLIT_STATE_FLOATS) is scratch (per-block maxima: no atomics, nothing to zero).  Planes hold scale*x;
  * consumers take `state + 1` as x_scale_dev / dz_scale_dev and undo the scale in their epilogue.  No host sync. */
-#define CG_SPLIT_STATE_FLOATS 258
-int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, float* state, cg_stream_t stream);
+#define CG_SPLIT_STATE_FLOATS 1026
+int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, float* state, int nslots,
+                         cg_stream_t stream);   /* nslots > 0: a producer kernel already left that many per-block maxima
+                                                   in state[2..] (cg_instnorm_bwd); 0: measure here */
+/* dz = dy * act'(y) straight into split form (cg_act_bwd + cg_split_f16_dynamic without the fp32 round trip); dz
+ * (optional) additionally receives the fp32 values */
+int cg_act_bwd_split(const float* dy, const float* y, size_t n, int act, void* out, size_t lo_elems, float* state,
+                     float* dz, cg_stream_t stream);
 /* split-precision data gradient (cg_conv2d_dgrad with dz pre-split by cg_split_f16_dynamic; needs Cout % 32 == 0);
  * ws: cg_conv2d_dgrad_workspace(g, nci) bytes (holds the re-laid-out, split weights) */
 int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, size_t dz_lo_elems, const float* dz_scale_dev,
@@ -169,7 +175,9 @@ int cg_instnorm_apply(const float* x, const float* mean, const float* rstd, cons
  * dgamma = sum dz*xhat, dbeta = sum dz (written at [n*gstride + c]; NULL for plain IN). */
 int cg_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, int gstride, float* dx, float* dgamma, float* dbeta, int N, int HW, int C,
-                    int act, void* ws, size_t ws_bytes, cg_stream_t stream);
+                    int act, void* ws, size_t ws_bytes, float* amax_state, int* amax_nslots, cg_stream_t stream);
+/* amax_state / amax_nslots (optional): the apply pass leaves per-block max |dx| in amax_state[2..] and their count in
+ * *amax_nslots (0 if it could not) for cg_split_f16_dynamic */
 
 /* ---- LayerNorm (networks.py:659-686): per-sample mean / unbiased std over C*H*W, x/(std+eps),
  *      per-channel gamma/beta --------------------------------------------------------------- */
