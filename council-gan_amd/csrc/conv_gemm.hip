@@ -1444,7 +1444,7 @@ extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_
     b.c[0].w_bytes = (unsigned)(w_lo_elems * 2);
     b.c[0].pad_ = (int32_t)w_span;
     const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, M) : tile_cfg;
-    const int bm = cfg == 3 ? 64 : 128;
+    const int bm = cfg == 3 ? 64 : (cfg == 5 ? 256 : 128);
     double* st_ptr = nullptr;
     if (rows_per_partial) {
         *rows_per_partial = 0;

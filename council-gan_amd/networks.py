@@ -390,11 +390,15 @@ class AdaINGen(nn.Module):
         return self.dec(content, images, return_mask)
 
     def assign_adain_params(self, adain_params, model):
-        for m in model.modules():
-            if m.__class__.__name__ == "AdaptiveInstanceNorm2d":
-                m.params = adain_params
-                m.bias = adain_params[:, m.boff:m.boff + m.num_features]        # views, no copy
-                m.weight = adain_params[:, m.goff:m.goff + m.num_features]
+        mods = self.__dict__.get('_adain_mods')
+        if mods is None or mods[0] is not model:
+            mods = (model, [m for m in model.modules() if m.__class__.__name__ == "AdaptiveInstanceNorm2d"])
+            self.__dict__['_adain_mods'] = mods
+        for m in mods[1]:
+            d = m.__dict__                     # plain attributes: skip nn.Module.__setattr__'s type dispatch
+            d['params'] = adain_params
+            d['bias'] = adain_params[:, m.boff:m.boff + m.num_features]        # views, no copy
+            d['weight'] = adain_params[:, m.goff:m.goff + m.num_features]
 
     def get_num_adain_params(self, model):
         return sum(2 * m.num_features for m in model.modules() if m.__class__.__name__ == "AdaptiveInstanceNorm2d")

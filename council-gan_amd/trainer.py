@@ -316,6 +316,27 @@ class Council_Trainer(nn.Module):
         # CPU RNG then upload, exactly as the reference (trainer_council.py:284-285,741,744,807-809)
         return torch.randn(n, self.style_dim, 1, 1)
 
+    def _upload(self, t):
+        """Host tensor -> device without stalling the host: a pageable-memory copy blocks until the stream has drained,
+        which would serialise the host with the GPU at every update; a small ring of pinned staging buffers (each guarded
+        by the event of its last copy) keeps the enqueue running ahead."""
+        ring = self.__dict__.setdefault('_pin_ring', {'i': 0, 'slots': [None] * 16})
+        k = ring['i'] % 16
+        ring['i'] += 1
+        slot = ring['slots'][k]
+        if slot is None or slot[0].numel() < t.numel():
+            slot = [torch.empty(max(t.numel(), 4096), dtype=torch.float32, pin_memory=True), None]
+            ring['slots'][k] = slot
+        if slot[1] is not None:
+            slot[1].synchronize()
+        stage = slot[0][:t.numel()].view(t.shape)
+        stage.copy_(t)
+        out = stage.to(self._device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        slot[1] = ev
+        return out
+
     # ------------------------------------------------------------------------------------
     # schedules (host integers), trainer_council.py:541-555, 784-801
     # ------------------------------------------------------------------------------------
@@ -339,10 +360,10 @@ class Council_Trainer(nn.Module):
             self.dis_opt_s[i].zero_grad()
         s = {}
         if self.do_a2b_conf:
-            s['a2b'] = self._noise(x_b.size(0)).to(self._device)
+            s['a2b'] = self._upload(self._noise(x_b.size(0)))
             self.loss_dis_a2b_s = [0] * self.council_size
         if self.do_b2a_conf:
-            s['b2a'] = self._noise(x_a.size(0)).to(self._device)
+            s['b2a'] = self._upload(self._noise(x_a.size(0)))
             self.loss_dis_b2a_s = [0] * self.council_size
         self.loss_dis_total_s = [0] * self.council_size
         self._fork()
@@ -391,8 +412,8 @@ class Council_Trainer(nn.Module):
         less = c['discriminetro_less_style_by']
         for d in self._dirs:
             if less != 0:
-                s_less[d] = (s[d] * less).to(self._device)
-            s[d] = s[d].to(self._device)
+                s_less[d] = self._upload(s[d] * less)
+            s[d] = self._upload(s[d])
         n_rel = c['numberOfCouncil_dis_relative_iteration']
 
         x_full = {d: {} for d in self._dirs}
@@ -460,8 +481,8 @@ class Council_Trainer(nn.Module):
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}
         for i in self.shard.local:
             self.gen_opt_s[i].zero_grad()
-        s_a = self._noise(x_a.size(0)).to(self._device)     # both drawn, s_a first (:284-285)
-        s_b = self._noise(x_b.size(0)).to(self._device)
+        s_a = self._upload(self._noise(x_a.size(0)))     # both drawn, s_a first (:284-285)
+        s_b = self._upload(self._noise(x_b.size(0)))
         s = {'a2b': s_b, 'b2a': s_a}
         fl = hp['focus_loss']
         focus_live = hp['iteration'] > fl['focus_loss_start_at_iter']
