@@ -350,3 +350,80 @@ def test_no_cpu_fallback(cga):
     """A CPU tensor must be rejected loudly, never computed by some fallback."""
     with pytest.raises(cga.hip.HipError):
         cga.ops.conv2d(torch.randn(1, 4, 4, 4), torch.randn(4, 4, 1, 1).cuda(), None)
+
+
+# ------------------------------------------------------------------------------------------
+# split-precision (fp16 x 3) kernels: forward, data gradient, weight gradient -- against fp64, with operands whose
+# magnitude is far outside fp16's comfortable range (the device-side power-of-two scale must absorb it)
+# ------------------------------------------------------------------------------------------
+X3_CASES = [
+    # name, N, H, W, Cin, Cout, K, stride, pad, up, x magnitude, dz magnitude
+    ("3x3_64to128", 2, 16, 16, 64, 128, 3, 1, 1, 0, 1.0, 1.0),
+    ("3x3_256to256_tiny_grad", 2, 32, 32, 256, 256, 3, 1, 1, 0, 1.0, 1e-7),
+    ("4x4s2_64to128_tiny_x", 2, 32, 32, 64, 128, 4, 2, 1, 0, 3e-5, 1e-3),
+    ("4x4s2_128to256_huge", 2, 32, 32, 128, 256, 4, 2, 1, 0, 4e3, 2e2),
+    ("up_3x3_128to64", 2, 16, 16, 128, 64, 3, 1, 1, 1, 1.0, 1e-4),
+    ("1x1_64to64", 2, 32, 32, 64, 64, 1, 1, 0, 0, 1.0, 1e-2),
+    ("1x1_512to512_few_rows", 3, 8, 8, 512, 512, 1, 1, 0, 0, 10.0, 1e-5),
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES, ids=[c[0] for c in X3_CASES])
+def test_split_precision_conv_kernels(cga, case):
+    from ctypes import byref
+    from council_gan_amd import hip, ops
+    _, N, H, W, Cin, Cout, K, stride, pad, up, xmag, gmag = case
+    lib = hip.load()
+    g = torch.Generator().manual_seed(sum(map(ord, case[0])))
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64) * xmag
+    w = torch.randn(Cout, Cin, K, K, generator=g, dtype=torch.float64) / np.sqrt(Cin * K * K)
+    b = torch.randn(Cout, generator=g, dtype=torch.float64) * xmag
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    inp = F.interpolate(xr, scale_factor=2, mode="nearest") if up else xr
+    yr = F.conv2d(F.pad(inp, (pad,) * 4), wr, br, stride=stride)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64) * gmag
+    yr.backward(gy)
+
+    xd, wd, bd, gyd = cl(dev(x)), cl(dev(w)), dev(b), cl(dev(gy))
+    geom = ops.fwd_geom(N, H, W, Cin, 0, up, K, K, stride, pad, Cout, 0)
+    with torch.no_grad():
+        xs = ops.split_f16_dynamic(xd)                      # device-side scale for x
+        ws = ops.split_f16(wd, hip.X3_WSCALE)
+        scale = float(xs.state[1])
+        peak = float(xd.abs().max()) * scale
+        assert 32.0 <= peak < 64.0 and np.log2(scale) == np.round(np.log2(scale)), (scale, peak)
+        y = ops.conv2d_x3(xs, ws, Cout, K, K, bd, stride, pad, "none", upsample=bool(up))
+        dzs = ops.split_f16_dynamic(gyd)
+        dx = ops.conv_dgrad_x3(geom, dzs, wd, 0, Cin)
+        dw = torch.zeros_like(wd)
+        db = torch.zeros(Cout, device="cuda")
+        assert lib.cg_conv2d_wgrad_x3_ok(byref(geom))
+        wsb = hip.workspace(lib.cg_conv2d_wgrad_workspace(byref(geom)))
+        hip.check(lib.cg_conv2d_wgrad_x3(byref(geom), xs.hi_ptr(), xs.lo, xs.scale_ptr(), dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(),
+                                         hip.ptr(dw), hip.ptr(db), 0, hip.ptr(wsb), wsb.numel(), hip.stream()), "wgrad_x3")
+    errs = {"fwd": rel(y, yr), "dx": rel(dx, xr.grad), "dw": rel(dw, wr.grad), "db": rel(db, br.grad)}
+    assert max(errs.values()) < 2e-5, errs          # fp32-class: the fp32-MFMA kernels sit at ~1e-6 on these shapes
+
+
+def test_instnorm_apply_split_and_act_bwd_split(cga):
+    """The split-emitting producers: AdaIN apply -> {hi, lo} planes, fused activation-backward -> scaled planes."""
+    from council_gan_amd import hip, ops
+    g = torch.Generator().manual_seed(11)
+    x = cl(dev(torch.randn(2, 64, 16, 16, generator=g) * 3 + 1))
+    res = cl(dev(torch.randn(2, 64, 16, 16, generator=g)))
+    with torch.no_grad():
+        y_ref = cga.ops.instance_norm(x, act="relu", residual=res)
+        y, ys = ops.instnorm_split(x, None, 0, 0, act="relu", residual=res, want_f32=True)
+        assert torch.equal(y, y_ref)
+        n = y.numel()
+        phys = y.permute(0, 2, 3, 1).reshape(-1)
+        recon = ys.buf[:n].float() + ys.buf[n:].float()
+        assert float((recon - phys).abs().max()) <= 2.0 ** -21 * float(phys.abs().max())
+        dy = cl(dev(torch.randn(2, 64, 16, 16, generator=g) * 1e-6))
+        yact = cl(dev(torch.randn(2, 64, 16, 16, generator=g)))
+        dz, dzs = ops.act_bwd_split(dy, yact, hip.ACT["lrelu"], True)
+        ref = dy * torch.where(yact > 0, torch.ones_like(yact), torch.full_like(yact, 0.2))
+        assert torch.allclose(dz, ref, rtol=1e-6, atol=0)
+        scale = float(dzs.state[1])
+        recon = (dzs.buf[:n].float() + dzs.buf[n:].float()) / scale
+        assert float((recon - ref.permute(0, 2, 3, 1).reshape(-1)).abs().max()) <= 2.0 ** -20 * float(ref.abs().max())
