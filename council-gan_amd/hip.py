@@ -144,9 +144,12 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise HipError("tensor on %s passed to a HIP kernel: the hot path has no CPU fallback" % t.device)
-    if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.float16):
+    if t.dtype not in _PTR_DTYPES:
         raise HipError("unsupported dtype %s" % t.dtype)
     return c_void_p(t.data_ptr())
+
+
+_PTR_DTYPES = frozenset((torch.float32, torch.int32, torch.uint8, torch.float16))
 
 
 _ws_cache = {}

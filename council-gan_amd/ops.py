@@ -40,9 +40,25 @@ def _off(t, elems):
 # ------------------------------------------------------------------------------------------
 # convolution geometry
 # ------------------------------------------------------------------------------------------
+_geom_cache = {}
+
+
 def fwd_geom(N, H, W, C1, C2, up, KH, KW, stride, pad, Cout, act):
     """Forward pass of ZeroPad2d(pad) -> Conv2d(KHxKW, stride) (networks.py:515-516) on an input that
-    is optionally read through a nearest 2x upsample (networks.py:385)."""
+    is optionally read through a nearest 2x upsample (networks.py:385).  Geometry structs are immutable once built
+    and cached by signature (a training step asks for the same few dozen thousands of times)."""
+    key = (N, H, W, C1, C2, up, KH, KW, stride, pad, Cout, act)
+    g = _geom_cache.get(key)
+    if g is not None:
+        return g
+    g = _build_geom(*key)
+    if len(_geom_cache) > 4096:
+        _geom_cache.clear()
+    _geom_cache[key] = g
+    return g
+
+
+def _build_geom(N, H, W, C1, C2, up, KH, KW, stride, pad, Cout, act):
     g = ConvGeom()
     Hl, Wl = H << up, W << up
     Ho = (Hl + 2 * pad - KH) // stride + 1
