@@ -1443,7 +1443,8 @@ extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_
     fill_class(b.c[0], g, (const float*)ws);
     b.c[0].w_bytes = (unsigned)(w_lo_elems * 2);
     b.c[0].pad_ = (int32_t)w_span;
-    const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, M) : tile_cfg;
+    const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, M, g->C1) : tile_cfg;
+    CG_CHECK_ARG((cfg != 6 && cfg != 7) || g->C1 % 64 == 0, "cg_conv2d_fwd_x3: tile configuration %d needs C %% 64 == 0", cfg);
     const int bm = cfg == 3 ? 64 : (cfg == 5 ? 256 : 128);
     double* st_ptr = nullptr;
     if (rows_per_partial) {
@@ -1800,7 +1801,7 @@ extern "C" int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, s
         b.c[c].pad_ = (int32_t)((wt_elems - p.w_off[c]) * 2 + wt_elems * 2);                       // span from this class's base
         m_total += b.c[c].M;
     }
-    return launch_x3_cfg(pick_x3_cfg(nci, m_total), b, p.ncls, dz_split, nullptr, dx, (unsigned)(dz_lo_elems * 2),
+    return launch_x3_cfg(pick_x3_cfg(nci, m_total, g->Cout), b, p.ncls, dz_split, nullptr, dx, (unsigned)(dz_lo_elems * 2),
                          (unsigned)(dz_lo_elems * 2 + dz_plane), 1.0f / CG_X3_WSCALE, dz_scale_dev, st, nullptr, nullptr, 0);
 }
 
