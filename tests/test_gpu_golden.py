@@ -327,7 +327,8 @@ def test_split_precision_decoder_matches_fp32(cga):
     O.seed_all(5)
     tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
     tr.cuda('cuda:0')
-    assert tr._split_fwd
+    if not tr._split_fwd:
+        pytest.skip("split-precision path disabled (CG_FORWARD_PRECISION=fp32)")
     x_a, _ = O.synthetic_batch(2, 64)
     x = tr._img(x_a)
     s = torch.randn(2, 64, 1, 1).cuda()
