@@ -19,10 +19,12 @@ for _ in range(3):
     print("enqueue %.1f ms   until GPU done %.1f ms" % (1e3 * (t1 - t0), 1e3 * (t2 - t0)))
 if len(sys.argv) > 1 and sys.argv[1] == "profile":
     import cProfile, pstats
+    torch.autograd.set_multithreading_enabled(False)      # backward nodes on this thread: visible to cProfile
+    step(); torch.cuda.synchronize()
     pr = cProfile.Profile()
     pr.enable()
     step()
     pr.disable()
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
-    st.sort_stats("tottime").print_stats(28)
+    st.sort_stats("tottime").print_stats(45)
