@@ -1445,7 +1445,7 @@ extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_
     b.c[0].pad_ = (int32_t)w_span;
     const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, M, g->C1) : tile_cfg;
     CG_CHECK_ARG((cfg != 6 && cfg != 7) || g->C1 % 64 == 0, "cg_conv2d_fwd_x3: tile configuration %d needs C %% 64 == 0", cfg);
-    const int bm = (cfg == 3 || cfg == 10) ? 64 : (cfg == 5 ? 256 : 128);
+    const int bm = (cfg == 3 || cfg == 10) ? 64 : ((cfg == 5 || cfg == 13) ? 256 : 128);
     double* st_ptr = nullptr;
     if (rows_per_partial) {
         *rows_per_partial = 0;

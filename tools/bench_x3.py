@@ -62,7 +62,7 @@ def main():
     print("fp16 (hi only)       : max-abs/max %.2e" % (float((y.cpu().double() - ref).abs().max()) / scale))
 
     # ---- throughput
-    print("%-34s %8s | %16s %16s %16s %16s %16s" % ("shape", "GFLOP", "fp32 pipe", "x3 128x128/8w", "x3 128x64/8w", "x3 DMA 128x128/8w", "x3 DMA 128x64/8w"))
+    print("%-34s %8s | %16s %16s %16s %16s %16s" % ("shape", "GFLOP", "fp32 pipe", "x3 128x128/8w", "x3 128x64/8w", "x3 128x128/16w", "x3 256x128/16w"))
     for si in (0, 1, 2, 3, 4, 12):
         name, N, H, W, Cin, Cout, K, stride, pad, up = SHAPES[si]
         g = ops.fwd_geom(N, H, W, Cin, 0, up, K, K, stride, pad, Cout, 1)
@@ -75,7 +75,7 @@ def main():
         flops = 2.0 * N * g.Ho * g.Wo * Cout * Cin * K * K
         reps = min(50, max(3, int(2e11 / flops / 4)))
         runs = [("fp32", lambda: hip.check(lib.cg_conv2d_fwd(byref(g), hip.ptr(x), None, hip.ptr(w), hip.ptr(b), hip.ptr(y), hip.stream()), "f"))]
-        for cfg in (1, 2, 8, 9):
+        for cfg in (1, 2, 12, 13):
             runs.append(("x3_%d" % cfg, (lambda c: (lambda: run_x3(lib, g, xs, ws, b, y2, c)))(cfg)))
         best = {k: 1e9 for k, _ in runs}
         for r in range(rounds + 1):
