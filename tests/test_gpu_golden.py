@@ -359,3 +359,87 @@ def test_split_precision_decoder_matches_fp32(cga):
     with tr._split_decode('a2b', 0):
         pass
     assert mgr.version != v0 and mgr.version == tr.gen_opt_s[0].version
+
+
+def _small_cfg():
+    import os
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "configs", "male2female_council_folder.yaml")))
+    cfg['gen'].update(dim=16, mlp_dim=32, n_res=2)
+    cfg['dis'].update(dim=16)
+    cfg['council']['council_size'] = 2
+    cfg['batch_size'] = 2
+    cfg['iteration'] = 60000
+    cfg['display_size'] = 2
+    return cfg
+
+
+def test_sample_layout_and_values(cga):
+    """`sample()` (trainer_council.py:643-733) returns the reference's 8-tuple; the a2b half is
+    (inputs repeated per member, masks, translation with the fixed style, translation with a fresh style)."""
+    cfg = _small_cfg()
+    O.seed_all(2)
+    tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+    tr.cuda('cuda:0')
+    x_a, x_b = O.synthetic_batch(2, 64)
+    out = tr.sample(x_a.cuda(), x_b.cuda())
+    assert len(out) == 8 and all(o is None for o in out[4:])            # b2a disabled in this config
+    xs, masks, x1, x2 = out[:4]
+    assert tuple(xs.shape) == tuple(x1.shape) == tuple(x2.shape) == (4, 3, 64, 64) and tuple(masks.shape) == (4, 3, 64, 64)
+    assert torch.equal(xs[0], xs[1]) and torch.equal(xs[0].cpu(), x_a[0])           # sample n, members 0 and 1
+    for t in (masks, x1, x2):
+        assert torch.isfinite(t).all()
+    assert float(masks.min()) >= 0.0 and float(masks.max()) <= 1.0
+    with torch.no_grad():                                                          # fixed-style output = a plain decode
+        gen = tr.gen_a2b_s[1]
+        xi = tr._img(x_a[:1].cuda())
+        ref = gen.decode(gen.encode_content(xi), tr.s_b[:1], xi)
+    assert rel_err(np_(x1[1:2]), np_(ref)) < 1e-5
+    assert not torch.equal(x1, x2)
+
+
+def test_save_resume_roundtrip(cga, tmp_path):
+    """checkpoint files, keys and tensors follow trainer_council.py:969-992 / 898-967, and a resumed
+    trainer continues bit-identically (weights, Adam moments, step counts).  Loss matching is switched off for the
+    continuation check: its 100-deep loss-history deques (trainer_council.py:131-138) are not part of the
+    reference's checkpoints either, so a resumed run restarts them at ones by design."""
+    import os
+    cfg = _small_cfg()
+    cfg['do_w_loss_matching'] = False
+    O.seed_all(4)
+    tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+    tr.cuda('cuda:0')
+    x_a, x_b = O.synthetic_batch(2, 64)
+    x_a, x_b = x_a.cuda(), x_b.cuda()
+
+    def one_iteration(t, seed):
+        O.seed_all(seed)
+        t.dis_update(x_a, x_b, cfg); t.dis_council_update(x_a, x_b, cfg); t.gen_update(x_a, x_b, cfg, 60000)
+
+    one_iteration(tr, 10)
+    tr.save(str(tmp_path), 122)
+    names = sorted(os.listdir(tmp_path))
+    assert names == sorted(['a2b_gen_%d_00000123.pt' % i for i in range(2)] + ['a2b_dis_%d_00000123.pt' % i for i in range(2)] +
+                           ['a2b_dis_council_%d_00000123.pt' % i for i in range(2)] + ['optimizer_%d.pt' % i for i in range(2)])
+    ck = torch.load(os.path.join(tmp_path, 'a2b_gen_0_00000123.pt'), map_location='cpu')
+    assert list(ck) == ['a2b'] and tuple(ck['a2b']['enc_content.model.0.conv.weight'].shape) == (16, 3, 7, 7)
+    opt = torch.load(os.path.join(tmp_path, 'optimizer_1.pt'), map_location='cpu')
+    assert sorted(opt) == ['dis', 'dis_council', 'gen'] and 'state' in opt['gen'] and 'param_groups' in opt['gen']
+
+    O.seed_all(99)                                           # different initial weights: everything must come from disk
+    tr2 = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+    tr2.cuda('cuda:0')
+    assert tr2.resume(str(tmp_path), cfg) == 123
+    for a, b in ((tr.gen_a2b_s, tr2.gen_a2b_s), (tr.dis_a2b_s, tr2.dis_a2b_s), (tr.dis_council_a2b_s, tr2.dis_council_a2b_s)):
+        for m, m2 in zip(a, b):
+            sa, sb = m.state_dict(), m2.state_dict()
+            assert list(sa) == list(sb)
+            for k in sa:
+                assert torch.equal(sa[k], sb[k]), k
+    one_iteration(tr, 11)
+    one_iteration(tr2, 11)
+    for m, m2 in zip(tr.gen_a2b_s, tr2.gen_a2b_s):
+        for (k, v), (_, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+            assert torch.equal(v, v2), k
+    f = lambda v: [float(t) for t in v]
+    assert f(tr.loss_gen_total_s) == f(tr2.loss_gen_total_s)
