@@ -58,7 +58,7 @@ def w_min_tflop(batch, size, council, n_rel):
 
 def build_config(args, world):
     cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", args.config)))
-    council = args.council if args.council else max(4, world)
+    council = args.council if args.council else 4      # more ranks than members: the members' batch is split (parallel.py)
     cfg['council']['council_size'] = council
     cfg['batch_size'] = args.batch
     cfg['new_size'] = cfg['crop_image_height'] = cfg['crop_image_width'] = args.size
@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="male2female_council_folder.yaml")
-    ap.add_argument("--council", type=int, default=0, help="override council size (default max(4, gpus))")
+    ap.add_argument("--council", type=int, default=0, help="override council size (default 4)")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -160,7 +160,12 @@ def main():
         "config": {"workload": "%s %dx%d council=%d batch=%d: dis_update + dis_council_update + gen_update "
                                "(train.py:237-251), fp32, all Adam steps" % (args.config.split('_')[0], args.size,
                                                                                args.size, council, args.batch),
-                   "members_per_gpu": council // world, "member_images_per_sec": round(value * council, 3),
+                   "members_per_gpu": council / world if council < world else council // world,
+                   "parallelism": ("%d council member(s) per GPU, one all-gather of generated images per iteration"
+                                   % (council // world) if world <= council else
+                                   "each council member on %d GPUs (batch split %d ways, gradient all-reduce inside the "
+                                   "member, image all-gather across members)" % (world // council, world // council)),
+                   "member_images_per_sec": round(value * council, 3),
                    "algorithmic_tflop_per_step": round(wmin, 3),
                    "forward_precision": ("fp16x3 split-precision MFMA on {hi,lo} fp16 planes, "
                                          "22 significand bits, fp32 accumulate (error below the fp32 kernel's round-off), "

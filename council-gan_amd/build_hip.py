@@ -14,7 +14,7 @@ DEPS = SRC + [os.path.join(HERE, "csrc", "cg_common.h"), os.path.join(HERE, "csr
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libcouncilgan_hip.so")
 STAMP = OUT + ".stamp"
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"] + os.environ.get("CG_HIPCC_FLAGS", "").split()
 
 
 def _digest():

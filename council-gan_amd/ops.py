@@ -745,7 +745,7 @@ class _FocusLoss(torch.autograd.Function):
     Returns (total, parts[3]) -- parts = the three unweighted criteria, for logging."""
 
     @staticmethod
-    def forward(ctx, mask, center, eps, w_zo, w_total, w_tv, use_abs, use_square):
+    def forward(ctx, mask, center, eps, w_zo, w_total, w_tv, use_abs, use_square, reduce):
         lib = _lib()
         mask = nhwc(mask)
         N, k, H, W = mask.shape
@@ -754,6 +754,11 @@ class _FocusLoss(torch.autograd.Function):
         ws = workspace(lib.cg_focus_workspace())
         check(lib.cg_focus_sums(ptr(mask), N, H, W, k, center, eps, ptr(sums), ptr(ws), ws.numel(), stream()),
               "cg_focus_sums")
+        if reduce is not None:
+            # data parallelism inside a member: with the MEAN of the replicas' sums every rank evaluates the full-batch
+            # criteria (the squared mask mean is not linear in the batch) and back-propagates world-size times its
+            # share, which the gradient averaging turns into the full-batch gradient
+            reduce(sums)
         check(lib.cg_focus_total(ptr(sums), mask.numel(), w_zo, w_total, w_tv, int(use_abs), int(use_square), ptr(out),
                                  stream()), "cg_focus_total")
         ctx.save_for_backward(mask, sums)
@@ -772,12 +777,12 @@ class _FocusLoss(torch.autograd.Function):
         d = torch.empty_like(mask)
         check(lib.cg_focus_bwd(ptr(mask), ptr(sums), ptr(g), N, H, W, k, center, eps, w_zo, w_total, w_tv, use_abs,
                                use_square, ptr(d), stream()), "cg_focus_bwd")
-        return d, None, None, None, None, None, None, None
+        return d, None, None, None, None, None, None, None, None
 
 
-def focus_loss(mask, center, eps, w_zo, w_total, w_tv, use_abs, use_square):
+def focus_loss(mask, center, eps, w_zo, w_total, w_tv, use_abs, use_square, reduce=None):
     return _FocusLoss.apply(mask, float(center), float(eps), float(w_zo), float(w_total), float(w_tv),
-                            bool(use_abs), bool(use_square))
+                            bool(use_abs), bool(use_square), reduce)
 
 
 class _L1Mean(torch.autograd.Function):

@@ -1,8 +1,9 @@
-"""Member-per-GPU sharding of the council -- new relative to the reference, which
+"""Sharding of the council over the GPUs of a node -- new relative to the reference, which
 is single-process.  Council members are independent models; the only per-iteration cross-member
 data dependency is that each member's council discriminator compares its own image with the
 OTHER members' generated images (trainer_council.py:853-856, 872-874).  So:
 
+  world_size <= council_size  (member sharding)
   * rank r owns members [r*L, (r+1)*L), L = council_size / world_size (their generator, both
     discriminators, three optimizers, loss-history rings, checkpoint files);
   * the batch, the style noise and the Python/NumPy RNG streams are replicated (same seeds on
@@ -11,63 +12,147 @@ OTHER members' generated images (trainer_council.py:853-856, 872-874).  So:
     ([L, B, H, W, C] fp32 per rank; 3.1 MB at B=4, 256x256) -- RCCL over xGMI on the GPU box
     (`backend="nccl"`), gloo in the CPU tests.  Latency-bound, never bandwidth-bound.
 
-This module has no dependency on the HIP library: the exchange works on any torch tensor, which
-is what lets the world_size-2 gloo tests exercise it on CPU."""
+  world_size = D * council_size  (one member per D ranks: data parallelism INSIDE a member)
+  * rank r holds a full replica of member r // D and works on samples [s*B/D, (s+1)*B/D) of every batch,
+    s = r % D; the networks have no cross-sample operator (instance / adaptive-instance norm are per sample), so
+    a batch slice is exact;
+  * the image exchange runs inside the SLICE group (the ranks with the same s: one per member);
+  * gradients are averaged inside the MEMBER group (the D replicas) with one all-reduce of the optimizer's flat
+    gradient buffer per optimizer step -- every loss is a batch mean, so the average of the replicas' gradients
+    is the full-batch gradient; the two statistics that are not linear in the batch (the squared mask mean of
+    the focus loss, the loss-matching history) are averaged before they are used (Council_Trainer).
+
+This module has no dependency on the HIP library: the collectives work on any torch tensor, which
+is what lets the gloo tests exercise them on CPU.  With the gloo backend device tensors are staged through the
+host (gloo is the test transport; RCCL takes device pointers)."""
 import os
 
 import torch
 import torch.distributed as dist
 
 
+def _is_nccl(group):
+    return dist.get_backend(group) == "nccl"
+
+
+def _all_gather(recv, send, group):
+    """recv[g] = rank g's send (flat views); device tensors go through the host unless the backend is RCCL."""
+    if send.is_cuda and not _is_nccl(group):
+        r, s = torch.empty(recv.shape, dtype=recv.dtype), send.cpu()
+        dist.all_gather_into_tensor(r.view(-1), s.view(-1), group=group)
+        recv.copy_(r)
+    else:
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+
+
+def _all_reduce_sum(t, group):
+    if t.is_cuda and not _is_nccl(group):
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+
+
 class CouncilShard:
-    def __init__(self, council_size, rank=0, world_size=1, group=None):
-        if council_size % world_size != 0:
-            raise ValueError("council_size %d must be a multiple of the number of ranks %d "
-                             "(intra-member data parallelism is a later row, SURVEY.md 8f.4)" % (council_size, world_size))
+    def __init__(self, council_size, rank=0, world_size=1, group=None, member_group=None, slice_group=None):
         self.council_size = council_size
         self.rank = rank
         self.world_size = world_size
         self.group = group
-        self.per_rank = council_size // world_size
-        self.local = list(range(rank * self.per_rank, (rank + 1) * self.per_rank))
+        if world_size <= council_size:
+            if council_size % world_size != 0:
+                raise ValueError("council_size %d must be a multiple of the number of ranks %d (or the number of "
+                                 "ranks a multiple of council_size)" % (council_size, world_size))
+            self.dp, self.slice_idx = 1, 0
+            self.per_rank = council_size // world_size
+            self.local = list(range(rank * self.per_rank, (rank + 1) * self.per_rank))
+            self.member_group, self.slice_group = None, group
+            self.slice_ranks = world_size
+        else:
+            if world_size % council_size != 0:
+                raise ValueError("the number of ranks %d must be a multiple of council_size %d (or divide it)"
+                                 % (world_size, council_size))
+            self.dp = world_size // council_size
+            self.slice_idx = rank % self.dp
+            self.per_rank = 1
+            self.local = [rank // self.dp]
+            if member_group is None or slice_group is None:
+                raise ValueError("data parallelism inside a member needs the member and slice process groups "
+                                 "(CouncilShard.from_env creates them)")
+            self.member_group, self.slice_group = member_group, slice_group
+            self.slice_ranks = council_size
 
     @classmethod
     def from_env(cls, council_size):
         """Single process unless torch.distributed has been initialised by the launcher."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return cls(council_size, dist.get_rank(), dist.get_world_size())
-        return cls(council_size)
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return cls(council_size)
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if world <= council_size or world % council_size != 0:
+            return cls(council_size, rank, world)
+        dp = world // council_size
+        member_group = slice_group = None
+        for m in range(council_size):             # every rank creates every group, in the same order
+            g = dist.new_group([m * dp + s for s in range(dp)])
+            if rank // dp == m:
+                member_group = g
+        for s in range(dp):
+            g = dist.new_group([m * dp + s for m in range(council_size)])
+            if rank % dp == s:
+                slice_group = g
+        return cls(council_size, rank, world, None, member_group, slice_group)
 
     def owner(self, member):
-        return member // self.per_rank
+        """First rank that holds `member`."""
+        return member * self.dp if self.dp > 1 else member // self.per_rank
 
+    # ---- batch slicing / replica averaging (no-ops unless a member spans several ranks) ------------------------
+    def batch_slice(self, t):
+        if self.dp == 1:
+            return t
+        b = t.shape[0]
+        if b % self.dp != 0:
+            raise ValueError("batch size %d is not a multiple of the %d ranks per council member" % (b, self.dp))
+        n = b // self.dp
+        return t[self.slice_idx * n:(self.slice_idx + 1) * n]
+
+    def replica_mean_(self, t):
+        """In-place mean over the replicas of this rank's member (gradients, the focus-loss sums, logged losses)."""
+        if self.dp > 1:
+            _all_reduce_sum(t, self.member_group)
+            t.mul_(1.0 / self.dp)
+        return t
+
+    # ---- the image exchange -------------------------------------------------------------------------------------
     def exchange(self, local_images):
         """local_images: list (len = per_rank) of logical-NCHW tensors (channels_last or contiguous).
-        Returns {member id: image} for EVERY member.  world_size == 1: no copy, no collective."""
+        Returns {member id: image} for EVERY member (of this rank's batch slice).  One rank: no copy, no collective."""
         if len(local_images) != self.per_rank:
             raise ValueError("expected %d local images" % self.per_rank)
         if self.world_size == 1:
             return {m: t for m, t in zip(self.local, local_images)}
         # stack the PHYSICAL (NHWC) layout so nothing is re-ordered before / after the collective
         send = torch.stack([t.permute(0, 2, 3, 1).contiguous() for t in local_images], 0)
-        recv = torch.empty((self.world_size,) + tuple(send.shape), dtype=send.dtype, device=send.device)
-        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+        recv = torch.empty((self.slice_ranks,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+        _all_gather(recv, send, self.slice_group)
+        me = self.local[0] // self.per_rank
         out = {}
-        for r in range(self.world_size):
+        for r in range(self.slice_ranks):
             for k in range(self.per_rank):
                 m = r * self.per_rank + k
-                out[m] = local_images[k] if r == self.rank else recv[r, k].permute(0, 3, 1, 2)
+                out[m] = local_images[k] if r == me else recv[r, k].permute(0, 3, 1, 2)
         return out
 
     def gather_scalars(self, values):
         """values: list of council_size floats with only the local entries meaningful -> full list
-        (logging only; off the hot path)."""
+        (logging only; off the hot path).  Replicas of a member contribute their batch-slice values' mean."""
         if self.world_size == 1:
             return list(values)
         t = torch.zeros(self.council_size, dtype=torch.float64)
         for m in self.local:
-            t[m] = float(values[m])
-        if dist.get_backend(self.group) == "nccl":
+            t[m] = float(values[m]) / self.dp
+        if _is_nccl(self.group):
             t = t.cuda()
         dist.all_reduce(t, group=self.group)
         return t.cpu().tolist()

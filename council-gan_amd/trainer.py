@@ -268,7 +268,10 @@ class Council_Trainer(nn.Module):
         ent = self._img_cache.get(slot) if slot is not None else None
         if ent is not None and ent[0] is x and ent[1] == x._version:
             return ent[2]
-        y = x.to(self._device, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+        y = x.to(self._device, dtype=torch.float32)
+        if slot is not None:
+            y = self.shard.batch_slice(y)                  # training batches: this rank's samples (parallel.py)
+        y = y.contiguous(memory_format=torch.channels_last)
         if slot is not None:
             self._img_cache[slot] = (x, x._version, y)     # holding `x` keeps its address from being recycled
         return y
@@ -316,6 +319,22 @@ class Council_Trainer(nn.Module):
         # CPU RNG then upload, exactly as the reference (trainer_council.py:284-285,741,744,807-809)
         return torch.randn(n, self.style_dim, 1, 1)
 
+    def _style(self, n):
+        """Style codes of a training batch: drawn for the WHOLE batch on every rank (replicated RNG stream), then cut
+        to this rank's samples when a member spans several ranks."""
+        return self.shard.batch_slice(self._noise(n))
+
+    def _full_batch(self, loss):
+        """Detached full-batch value of a batch-mean loss (the loss-matching history must be the same on every
+        replica of a member)."""
+        v = loss.detach()
+        return self.shard.replica_mean_(v.clone()) if self.shard.dp > 1 else v
+
+    def _sync_grads(self, opt):
+        """Full-batch gradient = mean of the member replicas' gradients: one all-reduce of the flat buffer."""
+        if self.shard.dp > 1:
+            self.shard.replica_mean_(opt.flat['grad'])
+
     def _upload(self, t):
         """Host tensor -> device without stalling the host: a pageable-memory copy blocks until the stream has drained,
         which would serialise the host with the GPU at every update; a small ring of pinned staging buffers (each guarded
@@ -360,10 +379,10 @@ class Council_Trainer(nn.Module):
             self.dis_opt_s[i].zero_grad()
         s = {}
         if self.do_a2b_conf:
-            s['a2b'] = self._upload(self._noise(x_b.size(0)))
+            s['a2b'] = self._upload(self._style(x_b.size(0)))
             self.loss_dis_a2b_s = [0] * self.council_size
         if self.do_b2a_conf:
-            s['b2a'] = self._upload(self._noise(x_a.size(0)))
+            s['b2a'] = self._upload(self._style(x_a.size(0)))
             self.loss_dis_b2a_s = [0] * self.council_size
         self.loss_dis_total_s = [0] * self.council_size
         self._fork()
@@ -383,6 +402,7 @@ class Council_Trainer(nn.Module):
                     total = l if total is None else total + l
                 self.loss_dis_total_s[i] = total.detach()
                 total.backward()
+                self._sync_grads(self.dis_opt_s[i])
                 self.dis_opt_s[i].step()
         self._join()
 
@@ -406,9 +426,9 @@ class Council_Trainer(nn.Module):
             self.dis_council_opt_s[i].zero_grad()
         s, s_less = {}, {}
         if self.do_b2a_conf:                       # s_a is drawn first here (:806-809)
-            s['b2a'] = self._noise(x_a.size(0))
+            s['b2a'] = self._style(x_a.size(0))
         if self.do_a2b_conf:
-            s['a2b'] = self._noise(x_b.size(0))
+            s['a2b'] = self._style(x_b.size(0))
         less = c['discriminetro_less_style_by']
         for d in self._dirs:
             if less != 0:
@@ -452,6 +472,7 @@ class Council_Trainer(nn.Module):
                     total = l if total is None else total + l
                 self.loss_dis_council_total_s[i] = total.detach()
                 total.backward()
+                self._sync_grads(self.dis_council_opt_s[i])
                 self.dis_council_opt_s[i].step()
         self._join()
 
@@ -481,8 +502,8 @@ class Council_Trainer(nn.Module):
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}
         for i in self.shard.local:
             self.gen_opt_s[i].zero_grad()
-        s_a = self._upload(self._noise(x_a.size(0)))     # both drawn, s_a first (:284-285)
-        s_b = self._upload(self._noise(x_b.size(0)))
+        s_a = self._upload(self._style(x_a.size(0)))     # both drawn, s_a first (:284-285)
+        s_b = self._upload(self._style(x_b.size(0)))
         s = {'a2b': s_b, 'b2a': s_a}
         fl = hp['focus_loss']
         focus_live = hp['iteration'] > fl['focus_loss_start_at_iter']
@@ -533,7 +554,8 @@ class Council_Trainer(nn.Module):
                         if focus_on:                                                   # :390-451
                             ftot, parts = ops.focus_loss(mask, fl['mask_zero_or_one_center'], fl['mask_zero_or_one_epsilon'],
                                                          hp['mask_zero_or_one_w'], hp['mask_total_w'], hp['mask_tv_w'],
-                                                         fl['mask_small_use_abs'], fl['mask_small_use_square'])
+                                                         fl['mask_small_use_abs'], fl['mask_small_use_square'],
+                                                         reduce=self.shard.replica_mean_ if self.shard.dp > 1 else None)
                             terms.append(ftot)
                             if hp['mask_zero_or_one_w'] != 0:
                                 getattr(self, 'loss_gen_mask_zero_one_%s_s' % ab[d])[i] = parts[0]
@@ -543,10 +565,11 @@ class Council_Trainer(nn.Module):
                                 getattr(self, 'loss_gen_mask_TV_%s_s' % ab[d])[i] = parts[2]
                         if hp['gan_w'] != 0:                                           # :498-529
                             adv = self._nets('dis', d)[i].calc_gen_loss(x_fake)
-                            getattr(self, 'loss_gen_adv_%s_s' % d)[i] = adv.detach()
+                            adv_full = self._full_batch(adv)
+                            getattr(self, 'loss_gen_adv_%s_s' % d)[i] = adv_full
                             ring_g, ring_c, w_dev = self._rings[d][i]
                             if self.do_w_loss_matching:
-                                check(lib.cg_ring_push(ptr(ring_g), self._ring_n, self._ring_pos[d][i], ptr(adv.detach()),
+                                check(lib.cg_ring_push(ptr(ring_g), self._ring_n, self._ring_pos[d][i], ptr(adv_full),
                                                        stream()), "cg_ring_push")
                                 self._ring_pos[d][i] += 1
                             terms.append(adv * float(hp['gan_w']))
@@ -555,7 +578,7 @@ class Council_Trainer(nn.Module):
                             if self.do_w_loss_matching:
                                 ring_g, ring_c, w_dev = self._rings[d][i]
                                 check(lib.cg_loss_match(ptr(ring_g), ptr(ring_c), self._ring_n, self._ring_pos_c[d][i],
-                                                        ptr(lc.detach()), ptr(w_dev), stream()), "cg_loss_match")
+                                                        ptr(self._full_batch(lc)), ptr(w_dev), stream()), "cg_loss_match")
                                 self._ring_pos_c[d][i] += 1
                                 setattr(self, 'w_match_%s_conf' % d, w_dev[0])
                                 lc = lc * w_dev[0]
@@ -566,6 +589,7 @@ class Council_Trainer(nn.Module):
                             total = t if total is None else total + t
                     self.loss_gen_total_s[i] = total.detach()
                     total.backward()
+                    self._sync_grads(self.gen_opt_s[i])
                     self.gen_opt_s[i].step()
         finally:
             self._join()

@@ -1,0 +1,111 @@
+"""Several ranks on ONE MI355X: the sharded trainer (member sharding, and data parallelism inside a member) must
+reproduce the single-process run.  The ranks share cuda:0 and talk over gloo (device tensors staged through the host
+by parallel.py) -- the box has one GPU, so RCCL itself is not exercised here, everything above the transport is:
+ownership, replicated RNG draws, batch slicing, the image exchange, gradient averaging, the focus-loss / loss-matching
+statistics."""
+import copy
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cfg(council):
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "configs", "male2female_council_folder.yaml")))
+    cfg['gen'].update(dim=16, mlp_dim=32, n_res=2)
+    cfg['dis'].update(dim=16)
+    cfg['council']['council_size'] = council
+    cfg['batch_size'] = 4
+    cfg['iteration'] = 60000
+    return cfg
+
+
+def _worker(rank, world, port, council, q):
+    import council_gan_amd as cga
+    from oracle import council_oracle as O
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK="0")
+        cga.init_distributed("gloo")
+    try:
+        cfg = _cfg(council)
+        O.seed_all(3)
+        tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+        tr.cuda('cuda:0')
+        x_a, x_b = O.synthetic_batch(4, 64)
+        x_a, x_b = x_a.cuda(), x_b.cuda()
+        rows = []
+        for it in range(2):
+            O.seed_all(20 + it)
+            tr.dis_update(x_a, x_b, cfg)
+            tr.dis_council_update(x_a, x_b, cfg)
+            tr.gen_update(x_a, x_b, cfg, 60000 + it)
+            row = []
+            for name in ('loss_dis_total_s', 'loss_dis_council_total_s', 'loss_gen_total_s', 'loss_gen_adv_a2b_s',
+                         'council_loss_ab_s'):
+                vals = [float(v) for v in getattr(tr, name)]
+                row.append(tr.shard.gather_scalars(vals))
+            rows.append(row)
+        # one weight tensor with a real gradient per local member, replicas must agree bit for bit
+        wsum = {m: float(tr.gen_a2b_s[m].state_dict()['dec.model.0.model.0.model.0.conv.weight'].double().sum())
+                for m in tr.shard.local}
+        q.put((rank, rows, wsum, tr.shard.dp))
+    finally:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def _run(world, council):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, council, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world,council", [(2, 4), (4, 2)])
+def test_sharded_trainer_matches_single_process(world, council):
+    ref = _run(1, council)[0]
+    res = _run(world, council)
+    dp = res[0][3]
+    assert dp == (world // council if world > council else 1)
+    for r in res:
+        assert r[1] == res[0][1], "gathered losses differ between ranks"
+    for it in range(2):
+        for got, want in zip(res[0][1][it], ref[1][it]):
+            for g, w in zip(got, want):
+                if dp == 1:
+                    assert g == w, (it, got, want)          # member sharding moves whole members: bit-identical
+                else:
+                    assert abs(g - w) <= 2e-4 * max(abs(w), 1e-3), (it, got, want)    # different summation order
+    wsum = {}
+    for r in res:
+        for m, v in r[2].items():
+            wsum.setdefault(m, []).append(v)
+    for m, vs in wsum.items():
+        assert all(v == vs[0] for v in vs), "replicas of member %d diverged" % m
+        if dp == 1:
+            assert vs[0] == ref[2][m]
+        else:
+            assert abs(vs[0] - ref[2][m]) <= 1e-3 * max(abs(ref[2][m]), 1.0)

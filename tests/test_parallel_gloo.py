@@ -86,3 +86,63 @@ def test_council_shard_world2_gloo(council):
 def test_council_must_divide_world():
     with pytest.raises(ValueError):
         cga.CouncilShard(3, rank=0, world_size=2)
+
+
+def _dp_worker(rank, world, port, council, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    cga.init_distributed("gloo")
+    try:
+        shard = cga.CouncilShard.from_env(council)
+        dp = world // council
+        assert (shard.dp, shard.slice_idx, shard.local, shard.per_rank) == (dp, rank % dp, [rank // dp], 1)
+        assert [shard.owner(m) for m in range(council)] == [m * dp for m in range(council)]
+        # this rank's samples of a replicated batch
+        batch = torch.arange(4 * 3, dtype=torch.float32).view(4, 3)
+        n = 4 // dp
+        assert torch.equal(shard.batch_slice(batch), batch[(rank % dp) * n:(rank % dp + 1) * n])
+        # image exchange inside the slice group: every member's image for THIS rank's samples
+        mine = _member_image(rank // dp, b=4)
+        got = shard.exchange([shard.batch_slice(mine)])
+        assert sorted(got) == list(range(council))
+        for m in range(council):
+            want = _member_image(m, b=4)[(rank % dp) * n:(rank % dp + 1) * n]
+            assert torch.equal(got[m].contiguous(), want.contiguous()), (rank, m)
+        # gradient averaging inside the member group
+        g = torch.full((5,), float(rank))
+        shard.replica_mean_(g)
+        base = (rank // dp) * dp
+        assert torch.equal(g, torch.full((5,), sum(range(base, base + dp)) / dp))
+        # logging: a member's value is the mean of its replicas' batch-slice values
+        vals = [-1.0] * council
+        vals[rank // dp] = 10.0 * (rank // dp) + (rank % dp)
+        full = shard.gather_scalars(vals)
+        assert full == [10.0 * m + (dp - 1) / 2.0 for m in range(council)]
+        q.put(rank)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_data_parallel_inside_member_world4_gloo():
+    """4 ranks, 2 members: every member is replicated on 2 ranks, each takes half of the batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 4, port, 2, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [0, 1, 2, 3]
+
+
+def test_shard_layouts():
+    s = cga.CouncilShard(4, rank=1, world_size=2)
+    assert (s.local, s.dp, s.per_rank) == ([2, 3], 1, 2)
+    with pytest.raises(ValueError):
+        cga.CouncilShard(4, rank=0, world_size=6)
+    with pytest.raises(ValueError):
+        cga.CouncilShard(4, rank=0, world_size=8)          # replicas need their process groups (from_env)
