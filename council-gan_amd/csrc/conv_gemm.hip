@@ -1469,9 +1469,9 @@ extern "C" int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t 
     if (blocks > 2048) blocks = 2048;
     hipStream_t st = cg_s(stream);
     if (nslots == 0) {      // nobody measured the tensor yet: one reduction pass; otherwise the producer filled the slots
-        hipLaunchKernelGGL(amax_kernel, dim3(CG_AMAX_BLOCKS), dim3(256), 0, st, x, n, state);
+        nslots = amax_blocks(n);
+        hipLaunchKernelGGL(amax_kernel, dim3(nslots), dim3(256), 0, st, x, n, state);
         CG_LAUNCH_CHECK("amax_kernel");
-        nslots = CG_AMAX_BLOCKS;
     }
     hipLaunchKernelGGL(split_f16_dyn_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)out, n, lo_elems, state,
                        nslots);
@@ -1751,10 +1751,11 @@ extern "C" int cg_act_bwd_split(const float* dy, const float* y, size_t n, int a
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipStream_t st = cg_s(stream);
-    hipLaunchKernelGGL(act_bwd_amax_kernel, dim3(CG_AMAX_BLOCKS), dim3(256), 0, st, dy, y, dz, n, act, state);
+    const int nslots = amax_blocks(n);
+    hipLaunchKernelGGL(act_bwd_amax_kernel, dim3(nslots), dim3(256), 0, st, dy, y, dz, n, act, state);
     CG_LAUNCH_CHECK("act_bwd_amax_kernel");
     hipLaunchKernelGGL(act_bwd_split_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, (_Float16*)out, n, lo_elems, act,
-                       state, CG_AMAX_BLOCKS);
+                       state, nslots);
     CG_LAUNCH_CHECK("act_bwd_split_kernel");
     return CG_OK;
 }

@@ -4,9 +4,11 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-rocprofv3 --kernel-trace --stats -d $O/raw -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/raw -o bench -- python $R/bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > $O/bench.json 2> $O/bench.err
 DB=$(find $O/raw -name "*.db" | head -1)
 python $R/tools/rocpd_summary.py $DB 70 > $O/kernel_stats.txt 2>&1
+python $R/tools/rocpd_timeline.py $DB 0.4 > $O/timeline.txt 2>&1
 rm -rf $O/raw
 head -75 $O/kernel_stats.txt
+cat $O/timeline.txt
 cut -c1-300 $O/bench.json
