@@ -6,13 +6,15 @@ One "step" = one train.py:237-251 iteration: dis_update + dis_council_update + g
 council members, all Adam steps included, inputs already resident in HBM, nothing skipped.
 Workload at N=1: BASELINE.json configs[2] -- male2female, 256x256, council=4, batch=4 (the
 configuration the metric is quoted on).  N=2,4: same problem, members sharded (strong scaling).
-N=8: council=8 (configs[4]), one member per GPU.  images/sec = batch * steps / wall-seconds, wall =
+N=8: same problem, every member on two GPUs, each taking half of the batch (gradient all-reduce inside
+the member, council-gan_amd/parallel.py).  images/sec = batch * steps / wall-seconds, wall =
 max over ranks between barrier+synchronize brackets.
 
 Rank 0 prints ONE JSON line; at N=1 it also carries
-  "roofline":     dominant kernel (fp32-MFMA implicit-GEMM conv) algorithmic TFLOP/s from HIP events
-                  on the launch stream vs the 157.3 TFLOP/s fp32 matrix peak, plus the whole-step figure
-                  (W_min of SURVEY.md 8d / step time);
+  "roofline":     dominant kernel (split-precision fp16x3 implicit-GEMM conv) algorithmic TFLOP/s from HIP
+                  events on the launch stream vs the peak of the datapath it runs on (fp16 MFMA / 3 passes =
+                  833 TFLOP/s; 157.3 for the fp32-MFMA kernels), plus the whole-step figure (W_min of
+                  SURVEY.md 8d / step time);
   "cpu_baseline": the oracle (CPU restatement of the reference) timed on this box's host cores on a
                   bounded sample of the same workload.
 """
