@@ -104,7 +104,11 @@ def main():
     args = ap.parse_args()
 
     import council_gan_amd as cga
-    rank, world, local_rank = cga.init_distributed("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    # CG_DIST_BACKEND=gloo + CG_SHARE_GPU=1: several ranks on ONE GPU (smoke test of the N>1 code path on a 1-GPU box)
+    backend = os.environ.get("CG_DIST_BACKEND", "nccl")
+    rank, world, local_rank = cga.init_distributed(backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if os.environ.get("CG_SHARE_GPU"):
+        local_rank = 0
     if world != max(args.gpus, 1) and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     device = torch.device("cuda", local_rank)
@@ -146,7 +150,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

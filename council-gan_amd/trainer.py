@@ -670,6 +670,8 @@ class Council_Trainer(nn.Module):
     # ------------------------------------------------------------------------------------
     def save(self, snapshot_dir, iterations):
         self._ready()
+        if self.shard.slice_idx != 0:      # replicas of a member hold identical weights: the first one writes
+            return
         for i in self.shard.local:
             tag = '_%d_%08d.pt' % (i, iterations + 1)
             for d in self._dirs:
