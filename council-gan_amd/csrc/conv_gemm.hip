@@ -1184,6 +1184,8 @@ int launch_pipe_batch(PipeBatch& b, int ncls, const float* x1, const float* bias
     return CG_OK;
 }
 
+// configurations whose launch forwards the statistics pointer to the kernel (the measurement variants 27-31 do not)
+bool pipe_cfg_has_stats(int cfg) { return (cfg >= 20 && cfg <= 26) || cfg == 32; }
 int pipe_cfg_bm(int cfg) { return cfg == 23 || cfg == 26 ? 64 : (cfg == 24 || cfg == 32 ? 256 : 128); }
 
 int launch_pipe_cfg(int cfg, PipeBatch& b, int ncls, const float* x1, const float* bias, float* y, unsigned x_bytes,
@@ -1193,9 +1195,9 @@ int launch_pipe_cfg(int cfg, PipeBatch& b, int ncls, const float* x1, const floa
         case 21: return launch_pipe_batch<128, 128, 64, 64>(b, ncls, x1, bias, y, x_bytes, st, stats);  // 4 waves
         case 22: return launch_pipe_batch<128, 64, 64, 32>(b, ncls, x1, bias, y, x_bytes, st, stats);   // 4 waves
         case 23: return launch_pipe_batch<64, 64, 32, 32>(b, ncls, x1, bias, y, x_bytes, st, stats);    // 4 waves
-        case 24: return launch_pipe_batch<256, 128, 64, 64>(b, ncls, x1, bias, y, x_bytes, st);  // 8 waves
-        case 25: return launch_pipe_batch<128, 64, 32, 32>(b, ncls, x1, bias, y, x_bytes, st);   // 8 waves
-        case 26: return launch_pipe_batch<64, 128, 32, 64>(b, ncls, x1, bias, y, x_bytes, st);   // 4 waves
+        case 24: return launch_pipe_batch<256, 128, 64, 64>(b, ncls, x1, bias, y, x_bytes, st, stats);  // 8 waves
+        case 25: return launch_pipe_batch<128, 64, 32, 32>(b, ncls, x1, bias, y, x_bytes, st, stats);   // 8 waves
+        case 26: return launch_pipe_batch<64, 128, 32, 64>(b, ncls, x1, bias, y, x_bytes, st, stats);   // 4 waves
         case 27: return launch_pipe_batch<128, 128, 64, 32, 2>(b, ncls, x1, bias, y, x_bytes, st);     // prefetch 2
         case 28: return launch_pipe_batch<128, 128, 64, 32, 1, 1>(b, ncls, x1, bias, y, x_bytes, st);  // ablation
         case 29: return launch_pipe_batch<128, 128, 64, 32, 1, 2>(b, ncls, x1, bias, y, x_bytes, st);  // ablation
@@ -1402,7 +1404,7 @@ extern "C" int cg_conv2d_fwd_stats(const cg_conv_geom* g, const float* x1, const
     const int cfg = pick_fwd_cfg(g, M, fast && pipe_ok(g, K));
     *rows_per_partial = 0;
     double* st_ptr = nullptr;
-    if (cfg >= 20 && stats && g->act == CG_ACT_NONE && g->osy == 1 && g->osx == 1) {
+    if (pipe_cfg_has_stats(cfg) && stats && g->act == CG_ACT_NONE && g->osy == 1 && g->osx == 1) {
         const int bm = pipe_cfg_bm(cfg);
         if ((g->Ho * g->Wo) % bm == 0 && stats_bytes >= (size_t)(M / bm) * g->Cout * 2 * sizeof(double)) {
             st_ptr = stats;

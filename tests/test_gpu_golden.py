@@ -443,3 +443,94 @@ def test_save_resume_roundtrip(cga, tmp_path):
             assert torch.equal(v, v2), k
     f = lambda v: [float(t) for t in v]
     assert f(tr.loss_gen_total_s) == f(tr2.loss_gen_total_s)
+
+
+def test_bench_size_iteration_split_vs_fp32_datapath(cga):
+    """BASELINE.json's full configuration (256x256, council 4, batch 4 -- every tile configuration the bench uses): one
+    whole iteration on the split-precision datapath against the same iteration on exact fp32 MFMA, same seeds.  The
+    oracle needs minutes at this size; the property checked instead is datapath independence: every loss of every member
+    agrees to 1e-4 (tolerance of the path: 1e-3), and a repeated run is bit-identical (no atomics, fixed reduction
+    orders)."""
+    import os
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "configs", "male2female_council_folder.yaml")))
+    cfg['council']['council_size'] = 4
+    cfg['batch_size'] = 4
+    cfg['iteration'] = 60000
+    x_a, x_b = O.synthetic_batch(4, 256)
+    x_a, x_b = x_a.cuda(), x_b.cuda()
+    names = ('loss_dis_total_s', 'loss_dis_council_total_s', 'loss_gen_total_s', 'loss_gen_adv_a2b_s',
+             'council_loss_ab_s', 'loss_gen_mask_zero_one_ab_s', 'loss_gen_mask_total_ab_s')
+
+    def run(precision):
+        c = copy.deepcopy(cfg)
+        c['cg_forward_precision'] = precision
+        O.seed_all(7)
+        tr = cga.Council_Trainer(c, 'cuda:0')
+        tr.cuda('cuda:0')
+        O.seed_all(8)
+        tr.dis_update(x_a, x_b, c); tr.dis_council_update(x_a, x_b, c); tr.gen_update(x_a, x_b, c, 60000)
+        out = {n: [float(v) for v in getattr(tr, n)] for n in names}
+        w = [float(m.state_dict()['dec.model.0.model.0.model.0.conv.weight'].double().sum()) for m in tr.gen_a2b_s]
+        del tr
+        return out, w
+
+    try:
+        split, w_split = run('split')
+        again, w_again = run('split')
+        exact, _ = run('fp32')
+    finally:
+        cga.ops.X3_FORWARD = cga.ops.X3_BACKWARD = cga.ops.X3_DYNAMIC_INPUT = True
+    assert split == again and w_split == w_again, "the iteration is not reproducible"
+    per = {}
+    for n in names:
+        for a, b in zip(split[n], exact[n]):
+            assert np.isfinite(a) and np.isfinite(b)
+            per[n] = max(per.get(n, 0.0), abs(a - b) / max(abs(b), 1e-6))
+    print("\n[bench-size iteration] relative loss difference split vs fp32 datapath:", {k: "%.1e" % v for k, v in per.items()})
+    worst = max(per.values())
+    assert worst < 1e-4, worst
+
+
+def test_bench_size_generator_forward_vs_oracle(cga):
+    """Generator forward at the bench resolution (256x256, full widths, batch 2) against the oracle in fp64, on all three
+    datapaths: the tape-free split-precision trunk, the general split-precision path, exact fp32 MFMA."""
+    import os
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "configs", "male2female_council_folder.yaml")))
+    cfg['council']['council_size'] = 2
+    cfg['batch_size'] = 2
+    cfg['iteration'] = 60000
+    O.seed_all(11)
+    tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+    sd = O.to_numpy_state(tr.gen_a2b_s[0].state_dict())
+    tr.cuda('cuda:0')
+    x_a, _ = O.synthetic_batch(2, 256)
+    s = torch.randn(2, cfg['gen']['style_dim'], 1, 1)
+    og = O.OracleGen({k: torch.as_tensor(np.asarray(v)).double() for k, v in sd.items()}, cfg['gen'])
+    with torch.no_grad():
+        oc = og.encode_content(x_a.double())
+        oimg, omask = og.decode(oc, s.double(), x_a.double(), return_mask=True)
+    gen = tr.gen_a2b_s[0]
+    x = tr._img(x_a)
+    sg = s.cuda()
+    res = {}
+    try:
+        with torch.no_grad():
+            for name, x3, trunk in (("fp32", False, False), ("split-general", True, False), ("split-trunk", True, True)):
+                cga.ops.X3_FORWARD = cga.ops.X3_DYNAMIC_INPUT = x3
+                c = gen.encode_content(x)
+                if trunk:
+                    with tr._split_decode('a2b', 0):
+                        img = gen.decode(c, sg, x)
+                        mask = gen.dec.mask_s
+                else:
+                    img = gen.decode(c, sg, x)
+                    mask = gen.dec.mask_s
+                res[name] = (rel_err(np_(c), oc.numpy()), rel_err(np_(img), oimg.numpy()), rel_err(np_(mask), omask.numpy()))
+    finally:
+        cga.ops.X3_FORWARD = cga.ops.X3_DYNAMIC_INPUT = tr._split_fwd
+    print("\n[256x256 generator forward vs fp64 oracle: content / image / mask]",
+          {k: tuple("%.1e" % e for e in v) for k, v in res.items()})
+    for k, v in res.items():
+        assert max(v) < ACT_TOL, (k, v)

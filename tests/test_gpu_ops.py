@@ -92,6 +92,38 @@ def test_conv2d(cga, case):
     assert max(errs.values()) < TOL, errs
 
 
+STATS_CASES = [
+    # name, N, H, W, Cin, Cout, up  (3x3, pad 1): every fp32 tile configuration pick_fwd_cfg can return for a layer that
+    # is followed by an instance norm, plus the generic (Cin = 3) kernel that leaves the statistics to the norm
+    ("cout64_many_tiles_128x64", 2, 64, 64, 128, 64, 1),
+    ("cout64_few_tiles_64x64", 2, 16, 16, 64, 64, 0),
+    ("cout128_few_tiles_64x64", 2, 64, 64, 64, 128, 0),
+    ("cout256_many_tiles_128x128", 4, 64, 64, 128, 256, 0),
+    ("cin3_generic", 2, 32, 32, 3, 64, 0),
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES, ids=[c[0] for c in STATS_CASES])
+def test_conv_epilogue_statistics_feed_instance_norm(cga, case):
+    """The {sum, sum of squares} an instance norm needs come out of the producing convolution's epilogue when the tile
+    configuration supports it (cg_conv2d_fwd_stats): conv -> IN -> ReLU through that route must equal the torch chain,
+    on the exact-fp32 kernels (the split-precision route is covered by the network-level tests)."""
+    _, N, H, W, Cin, Cout, up = case
+    torch.manual_seed(3)
+    x = cl(torch.randn(N, Cin, H, W).cuda())
+    w = cl((torch.randn(Cout, Cin, 3, 3) / np.sqrt(Cin * 9)).cuda())
+    b = torch.randn(Cout).cuda()
+    xi = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.relu(F.instance_norm(F.conv2d(xi.double(), w.double(), b.double(), padding=1)))
+    with torch.no_grad():
+        st = []
+        y = cga.ops.conv2d(x, w, b, 1, 1, "none", upsample=bool(up), stats=st)
+        fused = cga.ops.instance_norm(y, act="relu", stats=st)
+        plain = cga.ops.instance_norm(y, act="relu")
+    assert rel(plain, ref) < TOL, rel(plain, ref)
+    assert rel(fused, ref) < TOL, (rel(fused, ref), st[0][1] if st else None)
+
+
 def test_conv2d_accumulates_into_flat_grad(cga):
     """wgrad writes straight into a `_cg_grad` buffer (accumulate) and returns None to autograd."""
     g = torch.Generator().manual_seed(3)
