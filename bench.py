@@ -116,18 +116,18 @@ def main():
 
     cfg = build_config(args, world)
     council = cfg['council']['council_size']
-    from oracle import council_oracle as O      # only synthetic_batch / seed_all helpers + the cpu_baseline leg
-    O.seed_all(cfg['random_seed'])              # train.py:55-62 -- identical on every rank
+    cga.seed_everything(cfg['random_seed'])     # train.py:55-62 -- identical on every rank
     trainer = cga.Council_Trainer(cfg, str(device))
     state_fn = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        host_state = {d: {'gen': [O.to_numpy_state(m.state_dict()) for m in trainer._nets('gen', d)],
-                          'dis': [O.to_numpy_state(m.state_dict()) for m in trainer._nets('dis', d)],
-                          'dis_council': [O.to_numpy_state(m.state_dict()) for m in trainer._nets('disc', d)]}
+        to_np = lambda m: {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}   # the oracle's input format
+        host_state = {d: {'gen': [to_np(m) for m in trainer._nets('gen', d)],
+                          'dis': [to_np(m) for m in trainer._nets('dis', d)],
+                          'dis_council': [to_np(m) for m in trainer._nets('disc', d)]}
                       for d in trainer._dirs}
         state_fn = lambda: host_state
     trainer.cuda(device)
-    x_a, x_b = O.synthetic_batch(args.batch, args.size)
+    x_a, x_b = cga.synthetic_batch(args.batch, args.size)
     x_a, x_b = x_a.to(device), x_b.to(device)      # inputs resident in HBM before the timed region
 
     def step(it):

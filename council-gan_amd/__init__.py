@@ -10,6 +10,7 @@ from .networks import (AdaINGen, AdaptiveInstanceNorm2d, Conv2dBlock, ContentEnc
 from .optim import FlatAdam  # noqa: F401
 from .parallel import CouncilShard, init_distributed  # noqa: F401
 from .trainer import Council_Trainer  # noqa: F401
-from .utils import get_config, get_model_list, get_scheduler, weights_init  # noqa: F401
+from .utils import (get_config, get_model_list, get_scheduler, seed_everything, synthetic_batch,  # noqa: F401
+                    weights_init)
 
 __version__ = "0.1.0"

@@ -57,3 +57,23 @@ def get_model_list(dirname, key):
               if os.path.isfile(os.path.join(dirname, f)) and key in f and ".pt" in f]
     models.sort()
     return models[-1] if models else None
+
+
+def seed_everything(seed=1):
+    """train.py:55-62: Python, NumPy and torch generators from one seed (identical on every rank)."""
+    import random
+    import numpy as np
+    import torch
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def synthetic_batch(batch, size, seed=7):
+    """Benchmark input (no dataset in the image): fp32 images in [-1, 1), the range Normalize(0.5, 0.5) produces
+    (utils.py:124-126); both domains from one seeded generator."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    x_a = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
+    x_b = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
+    return x_a, x_b
