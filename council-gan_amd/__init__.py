@@ -7,6 +7,7 @@ from . import hip, ops  # noqa: F401
 from .networks import (AdaINGen, AdaptiveInstanceNorm2d, Conv2dBlock, ContentEncoder, Decoder_V2_atten,  # noqa: F401
                        LayerNorm, LinearBlock, MLP, MsImageDis, MsImageDisCouncil, ResBlock, ResBlocks,
                        StyleEncoder)
+from .input import DeviceInput  # noqa: F401
 from .optim import FlatAdam  # noqa: F401
 from .parallel import CouncilShard, init_distributed  # noqa: F401
 from .trainer import Council_Trainer  # noqa: F401

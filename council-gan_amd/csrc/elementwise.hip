@@ -396,6 +396,29 @@ extern "C" int cg_act_fwd(const float* x, float* y, size_t n, int act, cg_stream
     if (n == 0) return CG_OK;
     EW_LAUNCH(act_fwd_kernel, n, x, y, n, act);
 }
+// input pipeline tail: crop window + horizontal flip + ToTensor + Normalize, uint8 HWC -> fp32 NHWC.  One thread per
+// output pixel (C <= 4 channels: 3 bytes in, 12 bytes out); the divisions are IEEE fp32, as torch's div / sub / div.
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restrict__ src, int N, int Hs, int Ws, int C,
+                                                        const int32_t* __restrict__ crop_tl, const uint8_t* __restrict__ flip,
+                                                        int H, int W, float mean, float std, float* __restrict__ dst) {
+    const size_t total = (size_t)N * H * W;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(p % W), y = (int)((p / W) % H), n = (int)(p / ((size_t)W * H));
+        const int top = crop_tl ? crop_tl[2 * n] : 0, left = crop_tl ? crop_tl[2 * n + 1] : 0;
+        const int sx = left + ((flip && flip[n]) ? W - 1 - x : x);
+        const uint8_t* s = src + (((size_t)n * Hs + top + y) * Ws + sx) * C;
+        float* d = dst + p * C;
+        for (int c = 0; c < C; ++c) d[c] = __fdiv_rn(__fdiv_rn((float)s[c], 255.0f) - mean, std);
+    }
+}
+extern "C" int cg_u8_to_f32_nhwc(const uint8_t* src, int N, int Hs, int Ws, int C, const int32_t* crop_tl,
+                                 const uint8_t* flip, int H, int W, float mean, float std, float* dst, cg_stream_t stream) {
+    CG_CHECK_ARG(src && dst, "cg_u8_to_f32_nhwc: null pointer");
+    CG_CHECK_ARG(N > 0 && C >= 1 && C <= 4 && H > 0 && W > 0 && H <= Hs && W <= Ws && std != 0.f,
+                 "cg_u8_to_f32_nhwc: bad sizes (crop window larger than the image?)");
+    const size_t n = (size_t)N * H * W;
+    EW_LAUNCH(u8_to_f32_kernel, n, src, N, Hs, Ws, C, crop_tl, flip, H, W, mean, std, dst);
+}
 extern "C" int cg_fill(float* p, size_t n, float value, cg_stream_t stream) {
     CG_CHECK_ARG(p, "cg_fill: null pointer");
     if (n == 0) return CG_OK;

@@ -81,6 +81,7 @@ _SIGS = {
     "cg_l1_mean_fwd": (c_int, [_P, _P, c_size_t, _P, _P]),
     "cg_l1_mean_bwd": (c_int, [_P, _P, _P, c_size_t, _P, _P]),
     "cg_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    "cg_u8_to_f32_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_float, _P, _P]),
     "cg_fill": (c_int, [_P, c_size_t, c_float, _P]),
     "cg_add": (c_int, [_P, _P, _P, c_size_t, _P]),
     "cg_axpby": (c_int, [c_float, _P, c_float, _P, c_size_t, _P]),

@@ -267,6 +267,17 @@ int cg_loss_match(float* ring_gan, float* ring_council, int n, int pos, const fl
                   float* w_out, cg_stream_t stream);
 int cg_ring_push(float* ring, int n, int pos, const float* value, cg_stream_t stream);
 
+
+/* ---- input pipeline tail on the device ---------------------------------------
+ * The last three transforms of the reference's loader (utils.py:124-129,133-134): RandomCrop((H, W)) window,
+ * RandomHorizontalFlip, ToTensor + Normalize(mean, std) -- applied to a batch of decoded uint8 images:
+ *   dst[n][y][x][c] = ((float)src[n][top_n + y][left_n + (flip_n ? W-1-x : x)][c] / 255 - mean) / std
+ * src: [N][Hs][Ws][C] uint8 (PIL's HWC layout), dst: [N][H][W][C] fp32 = the NHWC batch the trainer consumes.
+ * crop_tl: N x {top, left} int32 on the device (NULL: top-left corner), flip: N bytes on the device (NULL: none).
+ * The geometric / colour transforms that torchvision applies to PIL images before these stay with the host loader. */
+int cg_u8_to_f32_nhwc(const uint8_t* src, int N, int Hs, int Ws, int C, const int32_t* crop_tl, const uint8_t* flip,
+                      int H, int W, float mean, float std, float* dst, cg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

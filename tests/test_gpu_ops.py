@@ -459,3 +459,34 @@ def test_instnorm_apply_split_and_act_bwd_split(cga):
         scale = float(dzs.state[1])
         recon = (dzs.buf[:n].float() + dzs.buf[n:].float()) / scale
         assert float((recon - ref.permute(0, 2, 3, 1).reshape(-1)).abs().max()) <= 2.0 ** -20 * float(ref.abs().max())
+
+
+def test_device_input_pipeline_matches_reference_transforms(cga):
+    """crop window + (deferred) horizontal flip + ToTensor + Normalize on the device, bit-exact against
+    the restated torchvision definitions (oracle/input_oracle.py); the trainer takes the result without a copy."""
+    from oracle import input_oracle as IO
+    rng = np.random.RandomState(5)
+    N, Hs, Ws, H, W = 5, 71, 83, 64, 64
+    imgs = rng.randint(0, 256, size=(N, Hs, Ws, 3)).astype(np.uint8)
+    imgs[0, :2, :2] = [[[0, 255, 1], [254, 127, 128]], [[3, 85, 170], [17, 34, 51]]]
+    tops, lefts = rng.randint(0, Hs - H + 1, size=N), rng.randint(0, Ws - W + 1, size=N)
+    flips = np.array([0, 1, 1, 0, 1], dtype=bool)
+    pipe = cga.DeviceInput('cuda:0', H, W)
+    # the reference flips the whole image first and then crops at (top, left): same pixels as cropping the original
+    # at the mirrored window and flipping the crop
+    crop = np.stack([tops, [IO.window_after_flip(l, Ws, W) if f else l for l, f in zip(lefts, flips)]], 1)
+    got = pipe(torch.from_numpy(imgs), crop_tl=crop, flip=flips)
+    assert got.shape == (N, 3, H, W) and got.is_contiguous(memory_format=torch.channels_last)
+    want = torch.stack([IO.sample(imgs[n], int(tops[n]), int(lefts[n]), H, W, flip_first=bool(flips[n])) for n in range(N)])
+    assert torch.equal(got.cpu(), want)
+    # Council_Trainer._img: `.to(device, float32).contiguous(channels_last)` is the identity on this tensor
+    assert got.to(got.device, dtype=torch.float32).contiguous(memory_format=torch.channels_last) is got
+    # no crop / no flip, full-size window; a second call reuses the staging ring
+    full = cga.DeviceInput('cuda:0', Hs, Ws)
+    for _ in range(6):
+        g2 = full(imgs)
+    assert torch.equal(g2.cpu(), torch.stack([IO.to_tensor_normalize(imgs[n]) for n in range(N)]))
+    with pytest.raises(ValueError):
+        pipe(imgs, crop_tl=np.array([[Hs - H + 1, 0]] * N))
+    with pytest.raises(ValueError):
+        cga.DeviceInput('cuda:0', 100, 64)(imgs)

@@ -183,3 +183,20 @@ def test_schedules_match_oracle():
             hp['iteration'] = it
             hp['council']['flipOnOff'] = flip
             assert cga.Council_Trainer._flip_state(hp) == O.council_flip_state(hp)
+
+
+def test_input_oracle_definitions():
+    """oracle/input_oracle.py against the arithmetic it restates (ToTensor = /255 in fp32, Normalize = (t - m) / s)."""
+    from oracle import input_oracle as IO
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, size=(9, 11, 3)).astype(np.uint8)
+    t = IO.to_tensor_normalize(img)
+    want = ((img.astype(np.float32) / np.float32(255)) - np.float32(0.5)) / np.float32(0.5)
+    assert t.dtype == torch.float32 and tuple(t.shape) == (3, 9, 11)
+    assert np.array_equal(t.numpy(), want.transpose(2, 0, 1))
+    assert float(t.min()) >= -1.0 and float(t.max()) <= 1.0
+    s = IO.sample(img, 2, 3, 4, 5, flip_first=True)
+    assert np.array_equal(s.numpy(), want[:, ::-1][2:6, 3:8].transpose(2, 0, 1))
+    # flip-then-crop == crop-the-mirrored-window-then-flip
+    l2 = IO.window_after_flip(3, 11, 5)
+    assert np.array_equal(s.numpy(), IO.sample(img, 2, l2, 4, 5).numpy()[:, :, ::-1])
