@@ -17,10 +17,15 @@ CL = torch.channels_last
 def main():
     cfgs = [int(c) for c in sys.argv[1].split(",")]
     shapes = [int(i) for i in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4, 13, 14]
+    table = list(SHAPES)
+    for spec in filter(None, os.environ.get("EXTRA_SHAPES", "").split(";")):     # name,N,H,W,Cin,Cout,K,stride,pad,up
+        f = spec.split(",")
+        table.append((f[0],) + tuple(int(v) for v in f[1:]))
+        shapes.append(len(table) - 1)
     lib = hip.load()
     print("%-38s | " % "shape" + " ".join("%22s" % ("cfg %d" % c) for c in cfgs))
     for si in shapes:
-        name, N, H, W, Cin, Cout, K, stride, pad, up = SHAPES[si]
+        name, N, H, W, Cin, Cout, K, stride, pad, up = table[si]
         g = ops.fwd_geom(N, H, W, Cin, 0, up, K, K, stride, pad, Cout, 1)
         x = torch.randn(N, Cin, H, W, device="cuda").contiguous(memory_format=CL)
         w = (torch.randn(Cout, Cin, K, K, device="cuda") * 0.05).contiguous(memory_format=CL)
