@@ -445,8 +445,17 @@ class Council_Trainer(nn.Module):
                     gen = self._nets('gen', d)[i]
                     content = self._content(d, i, x[d], need_grad=False)
                     with torch.no_grad(), self._split_decode(d, i):
-                        x_full[d][i] = gen.decode(content, s[d], x[d])
-                        x_cmp_local[d].append(gen.decode(content, s_less[d], x[d]) if less != 0 else x_full[d][i])
+                        if less != 0:
+                            # the two translations differ only in the style code: one decode over 2B samples (every
+                            # operator of the decoder is per sample) -- twice the rows per launch, half the launches
+                            b = x[d].shape[0]
+                            both = gen.decode(torch.cat((content, content), 0), torch.cat((s[d], s_less[d]), 0),
+                                              torch.cat((x[d], x[d]), 0))
+                            x_full[d][i] = both[:b]
+                            x_cmp_local[d].append(both[b:])
+                        else:
+                            x_full[d][i] = gen.decode(content, s[d], x[d])
+                            x_cmp_local[d].append(x_full[d][i])
         self._join()      # every member's council discriminator reads the OTHER members' images
         # the ONE cross-member exchange (trainer_council.py:853-856): every member's comparison image
         x_cmp = {d: self.shard.exchange(x_cmp_local[d]) for d in self._dirs}
