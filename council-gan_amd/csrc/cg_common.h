@@ -55,3 +55,30 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 static inline unsigned cg_div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+// ---- layout of the {hi, lo} fp16 form of a tensor (split-precision path) ------------------------------------------
+// CG_X3_INTERLEAVE = 1 (default): the planes are interleaved per 32 elements -- element i (flat physical index, NHWC /
+// [O][KH][KW][I]; channel counts are multiples of 32) has its hi half at cg_il(i) = 64*(i/32) + i%32 and its lo half
+// CG_X3_LO_ELEMS = 32 halves further, so the 32 channels x {hi, lo} of one K-slice of a pixel / weight row are ONE
+// 128-byte line (the planar layout fetched two half lines: +4...19 % on the forward / data-gradient kernels).
+// CG_X3_INTERLEAVE = 0: two separate planes, lo plane `lo_elems` halves after the hi plane (A/B builds).
+#ifndef CG_X3_INTERLEAVE
+#define CG_X3_INTERLEAVE 1
+#endif
+__host__ __device__ __forceinline__ size_t cg_il(size_t i) {
+#if CG_X3_INTERLEAVE
+    return ((i >> 5) << 6) | (i & 31);
+#else
+    return i;
+#endif
+}
+// byte offset of channel c (relative to its pixel / row, c a multiple of 8) and shift of a pixel / row base (elements -> bytes)
+__host__ __device__ __forceinline__ unsigned cg_il_cbytes(unsigned c) {
+#if CG_X3_INTERLEAVE
+    return ((c & ~31u) << 2) + ((c & 31u) << 1);
+#else
+    return c << 1;
+#endif
+}
+constexpr int CG_IL_SHIFT = CG_X3_INTERLEAVE ? 2 : 1;
+
+

@@ -1071,8 +1071,8 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
             if constexpr (SPLIT) {      // {hi, lo} fp16 planes of scale * w for the split-precision data-gradient
                 _Float16 h, l;
                 split_f16(tile[tx][r] * scale, h, l);
-                reinterpret_cast<_Float16*>(out)[o] = h;
-                reinterpret_cast<_Float16*>(out)[lo_elems + o] = l;
+                reinterpret_cast<_Float16*>(out)[cg_il(o)] = h;
+                reinterpret_cast<_Float16*>(out)[lo_elems + cg_il(o)] = l;
             } else {
                 out[o] = tile[tx][r];
             }
@@ -1218,6 +1218,15 @@ void fill_class(PipeClass& pc, const cg_conv_geom* g, const float* w) {
 }
 
 #include "conv_x3.inc"
+
+// {hi, lo} operand bookkeeping under the build's layout (cg_common.h): is the caller's lo offset valid for a tensor of
+// `plane_bytes` bytes per plane, and how many bytes do the two planes span from the hi pointer
+inline bool x3_lo_ok(size_t lo_elems, size_t plane_bytes) {
+    return CG_X3_INTERLEAVE ? (lo_elems == CG_X3_LO_ELEMS && plane_bytes % 64 == 0) : lo_elems * 2 >= plane_bytes;
+}
+inline size_t x3_span(size_t lo_elems, size_t plane_bytes) {
+    return CG_X3_INTERLEAVE ? 2 * plane_bytes : lo_elems * 2 + plane_bytes;
+}
 
 // the pipelined kernel needs: one source, channels a multiple of BK, operands addressable with 31-bit byte offsets
 bool pipe_ok(const cg_conv_geom* g, int K) {
@@ -1416,7 +1425,7 @@ extern "C" int cg_conv2d_fwd_stats(const cg_conv_geom* g, const float* x1, const
 
 // ---- split-precision forward (conv_x3.inc) --------------------------------------------------------
 extern "C" int cg_split_f16(const float* x, void* out, size_t n, size_t lo_elems, float scale, cg_stream_t stream) {
-    CG_CHECK_ARG(x && out && n > 0 && lo_elems >= n && scale > 0.f, "cg_split_f16: bad args");
+    CG_CHECK_ARG(x && out && n > 0 && x3_lo_ok(lo_elems, n * 2) && scale > 0.f, "cg_split_f16: bad args");
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
@@ -1433,12 +1442,13 @@ extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_
     int rc = validate_geom(g, "cg_conv2d_fwd_x3");
     if (rc) return rc;
     CG_CHECK_ARG(xs && ws && y && w_scale > 0.f, "cg_conv2d_fwd_x3: null pointer / bad scale");
-    CG_CHECK_ARG(!y_split || y_lo_elems >= (size_t)g->N * g->HoF * g->WoF * g->Cout, "cg_conv2d_fwd_x3: y lo plane overlaps");
+    CG_CHECK_ARG(!y_split || x3_lo_ok(y_lo_elems, (size_t)g->N * g->HoF * g->WoF * g->Cout * 2), "cg_conv2d_fwd_x3: bad y lo offset");
     const int K = g->T * g->C1;
     const int M = g->N * g->Ho * g->Wo;
     const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, w_plane = (size_t)g->Cout * K * 2;
-    CG_CHECK_ARG(x_lo_elems * 2 >= x_plane && w_lo_elems * 2 >= w_plane, "cg_conv2d_fwd_x3: lo plane overlaps the hi plane");
-    const size_t x_span = x_lo_elems * 2 + x_plane, w_span = w_lo_elems * 2 + w_plane;
+    CG_CHECK_ARG(x3_lo_ok(x_lo_elems, x_plane) && x3_lo_ok(w_lo_elems, w_plane),
+                 "cg_conv2d_fwd_x3: lo offset does not match the operand layout (CG_X3_LO_ELEMS)");
+    const size_t x_span = x3_span(x_lo_elems, x_plane), w_span = x3_span(w_lo_elems, w_plane);
     CG_CHECK_ARG(g->C2 == 0 && g->C1 % BK == 0 && x_span < (size_t)CG_OOB && w_span < (size_t)CG_OOB,
                  "cg_conv2d_fwd_x3: needs one source with C %% 32 == 0 and operands spanning < 2 GiB");
     PipeBatch b;
@@ -1464,7 +1474,7 @@ extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_
 
 extern "C" int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, float* state, int nslots,
                                     cg_stream_t stream) {
-    CG_CHECK_ARG(x && out && state && n > 0 && lo_elems >= n && nslots >= 0 && nslots <= CG_AMAX_MAX_SLOTS,
+    CG_CHECK_ARG(x && out && state && n > 0 && x3_lo_ok(lo_elems, n * 2) && nslots >= 0 && nslots <= CG_AMAX_MAX_SLOTS,
                  "cg_split_f16_dynamic: bad args");
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
@@ -1552,7 +1562,7 @@ int launch_wgrad_x3(const cg_conv_geom* g, const WgradPlan& p, const void* xs, s
     const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)M * g->Cout * 2;
     ProfScope prof(5, BM, BN, true, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
     hipLaunchKernelGGL((conv_wgrad_x3_kernel<BM, BN, WM, WN>), grid, block, 0, st, *g, xs, (unsigned)(x_lo * 2),
-                       (unsigned)(x_lo * 2 + x_plane), x_scale, dzs, (unsigned)(dz_lo * 2), (unsigned)(dz_lo * 2 + dz_plane),
+                       (unsigned)x3_span(x_lo, x_plane), x_scale, dzs, (unsigned)(dz_lo * 2), (unsigned)x3_span(dz_lo, dz_plane),
                        dz_scale, out, M, K, p.tiles_n, p.slices_per_split, want_bias, ilog2_exact(g->Ho * g->Wo),
                        ilog2_exact(g->Wo));
     CG_LAUNCH_CHECK("conv_wgrad_x3_kernel");
@@ -1564,7 +1574,7 @@ extern "C" int cg_conv2d_wgrad_x3_ok(const cg_conv_geom* g) {
     if (!g || g->T < 1 || g->T > CG_MAX_TAPS) return 0;
     const int M = g->N * g->Ho * g->Wo;
     WgradPlan p = plan_wgrad(g);
-    return wgrad_pipe_ok(g, p, M) && (g->Cout & 7) == 0 && (g->C1 & 7) == 0;
+    return wgrad_pipe_ok(g, p, M) && (g->Cout & 31) == 0 && (g->C1 & 31) == 0;
 }
 
 extern "C" int cg_conv2d_wgrad_x3(const cg_conv_geom* g, const void* xs, size_t x_lo_elems, const float* x_scale_dev,
@@ -1579,8 +1589,9 @@ extern "C" int cg_conv2d_wgrad_x3(const cg_conv_geom* g, const void* xs, size_t 
     const int K = g->T * g->C1;
     const int M = g->N * g->Ho * g->Wo;
     const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)M * g->Cout * 2;
-    CG_CHECK_ARG(x_lo_elems * 2 >= x_plane && dz_lo_elems * 2 >= dz_plane && x_lo_elems * 2 + x_plane < (size_t)CG_OOB &&
-                     dz_lo_elems * 2 + dz_plane < (size_t)CG_OOB, "cg_conv2d_wgrad_x3: operand planes out of range");
+    CG_CHECK_ARG(x3_lo_ok(x_lo_elems, x_plane) && x3_lo_ok(dz_lo_elems, dz_plane) && x3_span(x_lo_elems, x_plane) < (size_t)CG_OOB &&
+                     x3_span(dz_lo_elems, dz_plane) < (size_t)CG_OOB && g->Cout % 32 == 0 && g->C1 % 32 == 0,
+                 "cg_conv2d_wgrad_x3: operand planes out of range / lo offset does not match the layout");
     hipStream_t st = cg_s(stream);
     WgradPlan p = plan_wgrad(g);
     float* part = (float*)ws;
@@ -1748,7 +1759,7 @@ extern "C" int cg_conv2d_dgrad(const cg_conv_geom* g, const float* dz, const flo
 
 extern "C" int cg_act_bwd_split(const float* dy, const float* y, size_t n, int act, void* out, size_t lo_elems,
                                 float* state, float* dz, cg_stream_t stream) {
-    CG_CHECK_ARG(dy && y && out && state && n > 0 && lo_elems >= n, "cg_act_bwd_split: bad args");
+    CG_CHECK_ARG(dy && y && out && state && n > 0 && x3_lo_ok(lo_elems, n * 2), "cg_act_bwd_split: bad args");
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
@@ -1792,21 +1803,24 @@ extern "C" int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, s
         }
     const size_t wt_elems = p.ws_floats;          // one fp16 plane = as many elements as the fp32 layout had floats
     const size_t dz_plane = (size_t)g->N * g->Ho * g->Wo * g->Cout * 2;
-    CG_CHECK_ARG(dz_lo_elems * 2 >= dz_plane && dz_lo_elems * 2 + dz_plane < (size_t)CG_OOB && 4 * wt_elems < (size_t)CG_OOB,
-                 "cg_conv2d_dgrad_x3: operand planes out of range");
-    rc = launch_transpose(w, (float*)ws, g->Cout, g->T, Cin, ci0, nci, tt, nz, st, true, CG_X3_WSCALE, (unsigned)wt_elems);
+    CG_CHECK_ARG(x3_lo_ok(dz_lo_elems, dz_plane) && x3_span(dz_lo_elems, dz_plane) < (size_t)CG_OOB && 4 * wt_elems < (size_t)CG_OOB,
+                 "cg_conv2d_dgrad_x3: operand planes out of range / lo offset does not match the layout");
+    const size_t wt_lo = CG_X3_INTERLEAVE ? (size_t)CG_X3_LO_ELEMS : wt_elems;      // lo offset of the re-laid-out weights
+    rc = launch_transpose(w, (float*)ws, g->Cout, g->T, Cin, ci0, nci, tt, nz, st, true, CG_X3_WSCALE, (unsigned)wt_lo);
     if (rc) return rc;
     PipeBatch b;
     long m_total = 0;
     for (int c = 0; c < p.ncls; ++c) {
-        fill_class(b.c[c], &p.cg[c], (const float*)((const _Float16*)ws + p.w_off[c]));
-        b.c[c].w_bytes = (unsigned)(wt_elems * 2);                                                  // lo plane offset
-        b.c[c].pad_ = (int32_t)((wt_elems - p.w_off[c]) * 2 + wt_elems * 2);                       // span from this class's base
+        fill_class(b.c[c], &p.cg[c], (const float*)((const _Float16*)ws + cg_il(p.w_off[c])));     // class sizes: multiples of 32
+        b.c[c].w_bytes = (unsigned)(wt_lo * 2);                                                     // lo offset
+        b.c[c].pad_ = (int32_t)(4 * wt_elems - 2 * cg_il(p.w_off[c]));                             // span from this class's base
         m_total += b.c[c].M;
     }
     return launch_x3_cfg(pick_x3_cfg(nci, m_total, g->Cout), b, p.ncls, dz_split, nullptr, dx, (unsigned)(dz_lo_elems * 2),
-                         (unsigned)(dz_lo_elems * 2 + dz_plane), 1.0f / CG_X3_WSCALE, dz_scale_dev, st, nullptr, nullptr, 0);
+                         (unsigned)x3_span(dz_lo_elems, dz_plane), 1.0f / CG_X3_WSCALE, dz_scale_dev, st, nullptr, nullptr, 0);
 }
+
+extern "C" int cg_x3_interleaved(void) { return CG_X3_INTERLEAVE; }
 
 extern "C" int cg_debug_fetch(long long* host, int nwords) {
     CG_CHECK_ARG(host && nwords > 0 && nwords <= 4096 * CG_DBG_WORDS, "cg_debug_fetch: bad args");

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void in_apply_split_q(const float* __restrict_
     const int c = (i % (C >> 2)) << 2;
     const Quad q = load_quad(mean, rstd, gamma, beta, n, C, c, gs);
     const size_t base = (size_t)n * HW * C;
-    x += base; ys += base;
+    x += base; ys += cg_il(base);        // per-sample element counts are multiples of 32
     if (F32) y += base;
     if (RES) residual += base;
     for (; i < nq; i += step) {
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256) void in_apply_split_q(const float* __restrict_
             h[k] = (_Float16)fminf(fmaxf(o[k], -65504.f), 65504.f);
             l[k] = (_Float16)(o[k] - (float)h[k]);
         }
-        *reinterpret_cast<uint2*>(ys + 4 * (size_t)i) = *reinterpret_cast<const uint2*>(h);
-        *reinterpret_cast<uint2*>(ys + lo_elems + 4 * (size_t)i) = *reinterpret_cast<const uint2*>(l);
+        *reinterpret_cast<uint2*>(ys + cg_il(4 * (size_t)i)) = *reinterpret_cast<const uint2*>(h);
+        *reinterpret_cast<uint2*>(ys + lo_elems + cg_il(4 * (size_t)i)) = *reinterpret_cast<const uint2*>(l);
     }
 }
 
@@ -614,7 +614,8 @@ extern "C" int cg_instnorm_apply_split(const float* x, const float* mean, const 
                                        size_t y_lo_elems, int N, int HW, int C, int act, cg_stream_t stream) {
     CG_CHECK_ARG(x && mean && rstd && y_split && N > 0 && HW > 0 && C > 0, "cg_instnorm_apply_split: bad args");
     CG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "cg_instnorm_apply_split: gamma and beta go together");
-    CG_CHECK_ARG(quad_ok(C) && (size_t)HW * C < (size_t)0x7fffffff && y_lo_elems >= (size_t)N * HW * C,
+    CG_CHECK_ARG(quad_ok(C) && (size_t)HW * C < (size_t)0x7fffffff &&
+                     (CG_X3_INTERLEAVE ? (y_lo_elems == CG_X3_LO_ELEMS && C % 32 == 0) : y_lo_elems >= (size_t)N * HW * C),
                  "cg_instnorm_apply_split: channel count %d / plane offset not supported", C);
     dim3 grid(quad_grid(HW, C, N), N);
     _Float16* ys = (_Float16*)y_split;

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcouncilgan_hip.so")
 
 ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "tanh": 3}
 MAX_TAPS = 64
+X3_LO_ELEMS = 32             # CG_X3_LO_ELEMS
 X3_WSCALE = 1024.0      # CG_X3_WSCALE: power-of-two pre-scale of split-precision weights
 SPLIT_STATE_FLOATS = 1026  # CG_SPLIT_STATE_FLOATS
 
@@ -82,6 +83,7 @@ _SIGS = {
     "cg_l1_mean_bwd": (c_int, [_P, _P, _P, c_size_t, _P, _P]),
     "cg_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
     "cg_u8_to_f32_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_float, _P, _P]),
+    "cg_x3_interleaved": (c_int, []),
     "cg_fill": (c_int, [_P, c_size_t, c_float, _P]),
     "cg_add": (c_int, [_P, _P, _P, c_size_t, _P]),
     "cg_axpby": (c_int, [c_float, _P, c_float, _P, c_size_t, _P]),

@@ -433,10 +433,28 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 # ------------------------------------------------------------------------------------------
 # split-precision ("fp16 x 3") forward path -- tape-free passes only
 # ------------------------------------------------------------------------------------------
+_X3_IL = None
+
+
+def x3_interleaved():
+    """Layout of the library's {hi, lo} tensors (include/council_gan_hip.h, CG_X3_LO_ELEMS): interleaved per 32 elements
+    (the default build) or two separate planes (A/B builds)."""
+    global _X3_IL
+    if _X3_IL is None:
+        _X3_IL = bool(_lib().cg_x3_interleaved())
+    return _X3_IL
+
+
+def x3_lo(numel):
+    """The `*_lo_elems` argument for a split tensor of `numel` elements."""
+    return hip.X3_LO_ELEMS if x3_interleaved() else numel
+
+
 class SplitTensor:
-    """A tensor stored as two fp16 planes (hi = f16(s*v), lo = f16(s*v - hi)), physical NHWC / [O][KH][KW][I].
-    `buf` is a flat fp16 tensor; the hi plane starts at element `off`, the lo plane `lo` elements later; `scale` is
-    the power of two s the values were multiplied by (weights: hip.X3_WSCALE)."""
+    """A tensor stored as fp16 halves hi = f16(s*v), lo = f16(s*v - hi), physical NHWC / [O][KH][KW][I].
+    `buf` is a flat fp16 tensor of 2 x numel halves; the tensor starts at ELEMENT `off` of it (a multiple of 32) and its
+    lo halves sit `lo` halves after the hi halves (x3_lo); `scale` is the power of two s the values were multiplied by
+    (weights: hip.X3_WSCALE)."""
 
     def __init__(self, buf, shape, off=0, lo=None, scale=1.0, state=None):
         self.buf, self.shape, self.off, self.scale = buf, tuple(shape), off, scale
@@ -445,13 +463,25 @@ class SplitTensor:
         for d in shape:
             n *= d
         self.numel = n
-        self.lo = n if lo is None else lo
+        self.lo = x3_lo(n) if lo is None else lo
 
     def hi_ptr(self):
+        if x3_interleaved():
+            if self.off % 32:
+                raise hip.HipError("a split tensor must start on a 32-element boundary of its buffer")
+            return c_void_p(self.buf.data_ptr() + 4 * self.off)
         return c_void_p(self.buf.data_ptr() + 2 * self.off)
 
     def scale_ptr(self):
         return None if self.state is None else c_void_p(self.state.data_ptr() + 4)
+
+    def to_float(self):
+        """hi + lo as a flat fp32 tensor in the physical element order, still multiplied by the scale (debug / tests)."""
+        n = self.numel
+        if x3_interleaved():
+            g = self.buf[2 * self.off:2 * (self.off + n)].view(-1, 64).float()
+            return (g[:, :32] + g[:, 32:]).reshape(-1)
+        return self.buf[self.off:self.off + n].float() + self.buf[self.off + self.lo:self.off + self.lo + n].float()
 
 
 class SplitWeights:
@@ -475,11 +505,11 @@ class SplitWeights:
             total = f['data'].numel()
             if self.buf is None or self.buf.numel() != 2 * total or self.buf.device != f['data'].device:
                 self.buf = torch.empty(2 * total, dtype=torch.float16, device=f['data'].device)
-            check(_lib().cg_split_f16(ptr(f['data']), ptr(self.buf), total, total, hip.X3_WSCALE, stream()), "cg_split_f16")
+            check(_lib().cg_split_f16(ptr(f['data']), ptr(self.buf), total, x3_lo(total), hip.X3_WSCALE, stream()), "cg_split_f16")
             self.views = {}
             for p, o in zip(opt._params, f['offs']):
                 if p.dim() == 4:
-                    self.views[id(p)] = SplitTensor(self.buf, (p.shape[0], p.shape[2], p.shape[3], p.shape[1]), off=o, lo=total,
+                    self.views[id(p)] = SplitTensor(self.buf, (p.shape[0], p.shape[2], p.shape[3], p.shape[1]), off=o, lo=x3_lo(total),
                                                     scale=hip.X3_WSCALE)
             self.version = opt.version
         return self.views.get(id(weight))
@@ -495,7 +525,7 @@ def split_f16(x, scale=1.0):
         raise hip.HipError("split-precision tensors carry no gradient: use them under torch.no_grad() only")
     x = nhwc(x)
     buf = torch.empty(2 * x.numel(), dtype=torch.float16, device=x.device)
-    check(_lib().cg_split_f16(ptr(x), ptr(buf), x.numel(), x.numel(), float(scale), stream()), "cg_split_f16")
+    check(_lib().cg_split_f16(ptr(x), ptr(buf), x.numel(), x3_lo(x.numel()), float(scale), stream()), "cg_split_f16")
     return SplitTensor(buf, x.shape, scale=scale)
 
 
@@ -508,7 +538,7 @@ def split_f16_dynamic(x, amax=None):
         state, nslots = amax
     else:
         state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=x.device), 0
-    check(_lib().cg_split_f16_dynamic(ptr(x), ptr(buf), x.numel(), x.numel(), ptr(state), nslots, stream()),
+    check(_lib().cg_split_f16_dynamic(ptr(x), ptr(buf), x.numel(), x3_lo(x.numel()), ptr(state), nslots, stream()),
           "cg_split_f16_dynamic")
     return SplitTensor(buf, x.shape, state=state)
 
@@ -518,7 +548,7 @@ def act_bwd_split(dy, y, act, want_fp32):
     buf = torch.empty(2 * dy.numel(), dtype=torch.float16, device=dy.device)
     state = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=dy.device)
     dz = torch.empty_like(dy) if want_fp32 else None
-    check(_lib().cg_act_bwd_split(ptr(dy), ptr(y), dy.numel(), act, ptr(buf), dy.numel(), ptr(state), ptr(dz), stream()),
+    check(_lib().cg_act_bwd_split(ptr(dy), ptr(y), dy.numel(), act, ptr(buf), x3_lo(dy.numel()), ptr(state), ptr(dz), stream()),
           "cg_act_bwd_split")
     return dz, SplitTensor(buf, dy.shape, state=state)
 

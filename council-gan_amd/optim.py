@@ -46,12 +46,13 @@ class FlatAdam(torch.optim.Optimizer):
         if self._flat is not None and self._flat["data"].device == device:
             return
         sizes = [p.numel() for p in self._params]
-        # every parameter starts on a 32-byte boundary of the flat buffers, so that the fp16 {hi, lo} mirror of the
-        # buffer (ops.SplitWeights) is 16-byte aligned per tensor (buffer_load_dwordx4); padding stays zero for ever
+        # every parameter starts on a 32-ELEMENT boundary of the flat buffers: the fp16 {hi, lo} mirror of the buffer
+        # (ops.SplitWeights) interleaves the halves per 32 elements of the flat index, so a tensor's groups must not
+        # straddle its start (and its 128-byte lines are aligned); padding stays zero for ever
         starts, total = [], 0
         for n in sizes:
             starts.append(total)
-            total = (total + n + 7) & ~7
+            total = (total + n + 31) & ~31
         old = self._flat
         data = torch.zeros(total, dtype=torch.float32, device=device)
         grad = torch.zeros(total, dtype=torch.float32, device=device)

@@ -86,6 +86,14 @@ int cg_conv2d_fwd_stats(const cg_conv_geom* g, const float* x1, const float* x2,
  * same geometry, epilogue and optional instance-norm partials as cg_conv2d_fwd_stats.  tile_cfg -1 = heuristic.
  * The lo plane of an operand starts *_lo_elems halves after its hi plane. */
 #define CG_X3_WSCALE 1024.0f
+/* Layout of a {hi, lo} tensor.  The library is built with the halves interleaved per 32 elements: element i (flat
+ * physical index; every split tensor has a channel count that is a multiple of 32) has its hi half at
+ * 64*(i/32) + i%32 and its lo half CG_X3_LO_ELEMS halves further on, so one 32-channel K-slice of a pixel / weight row
+ * is one 128-byte line.  Every `*_lo_elems` argument below must then be CG_X3_LO_ELEMS, and a sub-tensor that starts
+ * at element `off` (a multiple of 32) starts 4*off bytes into the buffer.  cg_x3_interleaved() returns 0 for an A/B
+ * build with two separate planes (-DCG_X3_INTERLEAVE=0), where `*_lo_elems` is the distance of the lo plane in halves. */
+#define CG_X3_LO_ELEMS 32
+int cg_x3_interleaved(void);
 int cg_split_f16(const float* x, void* out, size_t n, size_t lo_elems, float scale, cg_stream_t stream);
 int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* x_hi, size_t x_lo_elems, const void* w_hi, size_t w_lo_elems,
                      float w_scale, const float* x_scale_dev, const float* bias, float* y, void* y_split,

@@ -149,9 +149,10 @@ def test_flat_adam_views_and_state_dict_on_host():
     opt = cga.FlatAdam(params, lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-4)
     opt.materialize('cpu')
     f = opt.flat
-    # every parameter starts on a 32-byte (8-element) boundary of the flat buffer; the padding is zero
-    assert all(o % 8 == 0 for o in f["offs"]) and f["offs"] == [0, 288, 296, 312]
-    assert f["data"].numel() == 320 and float(f["data"][312 + 3:].abs().sum()) == 0.0
+    # every parameter starts on a 32-element boundary of the flat buffer (the interleaved fp16 mirror); the padding is zero
+    assert all(o % 32 == 0 for o in f["offs"]) and f["offs"] == [0, 288, 320, 352]
+    assert f["data"].numel() == 384 and float(f["data"][352 + 3:].abs().sum()) == 0.0
+    assert float(f["data"][296:320].abs().sum()) == 0.0 and float(f["data"][335:352].abs().sum()) == 0.0
     for p, b in zip(params, before):
         assert torch.equal(p.detach(), b)
         assert p.data.untyped_storage().data_ptr() == f["data"].untyped_storage().data_ptr()

@@ -19,12 +19,12 @@ CL = torch.channels_last
 def split(lib, t, scale=1.0):
     """fp32 tensor (physical layout kept) -> [2, numel] fp16 planes"""
     out = torch.empty(2 * t.numel(), dtype=torch.float16, device=t.device)
-    hip.check(lib.cg_split_f16(hip.ptr(t), hip.ptr(out), t.numel(), t.numel(), scale, hip.stream()), "split")
+    hip.check(lib.cg_split_f16(hip.ptr(t), hip.ptr(out), t.numel(), ops.x3_lo(t.numel()), scale, hip.stream()), "split")
     return out
 
 
 def run_x3(lib, g, xs, ws, b, y, cfg):
-    hip.check(lib.cg_conv2d_fwd_x3(byref(g), hip.ptr(xs), xs.numel() // 2, hip.ptr(ws), ws.numel() // 2, hip.X3_WSCALE, None,
+    hip.check(lib.cg_conv2d_fwd_x3(byref(g), hip.ptr(xs), ops.x3_lo(xs.numel() // 2), hip.ptr(ws), ops.x3_lo(ws.numel() // 2), hip.X3_WSCALE, None,
                                    hip.ptr(b), hip.ptr(y), None, 0, None, 0, None, cfg, hip.stream()), "x3")
 
 
@@ -55,8 +55,12 @@ def main():
         print("fp16x3 cfg %d         : max-abs/max %.2e   rms-rel %.2e" % (cfg, e, r))
     # plain fp16 (hi*hi only) for scale: emulate by zeroing the lo planes
     xs0, ws0 = xs.clone(), ws.clone()
-    xs0[xd.numel():] = 0
-    ws0[wd.numel():] = 0
+    if ops.x3_interleaved():
+        xs0.view(-1, 64)[:, 32:] = 0
+        ws0.view(-1, 64)[:, 32:] = 0
+    else:
+        xs0[xd.numel():] = 0
+        ws0[wd.numel():] = 0
     y = torch.empty_like(y32)
     run_x3(lib, g, xs0, ws0, bd, y, 0)
     print("fp16 (hi only)       : max-abs/max %.2e" % (float((y.cpu().double() - ref).abs().max()) / scale))
