@@ -1570,6 +1570,29 @@ int launch_wgrad_x3(const cg_conv_geom* g, const WgradPlan& p, const void* xs, s
 }
 }  // namespace
 
+#if CG_X3_INTERLEAVE
+namespace {
+template <int BM, int BN, int WM, int WN>
+int launch_wgrad_x3t(const cg_conv_geom* g, const WgradPlan& p, const void* xs, size_t x_lo, const float* x_scale,
+                     const void* dzs, size_t dz_lo, const float* dz_scale, float* out, int M, int K, int want_bias,
+                     hipStream_t st) {
+    dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits), block((BM / WM) * (BN / WN) * 64);
+    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)M * g->Cout * 2;
+    ProfScope prof(5, BM, BN, true, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
+    hipLaunchKernelGGL((conv_wgrad_x3t_kernel<BM, BN, WM, WN>), grid, block, 0, st, *g, xs, (unsigned)x3_span(x_lo, x_plane),
+                       x_scale, dzs, (unsigned)x3_span(dz_lo, dz_plane), dz_scale, out, M, K, p.tiles_n, p.slices_per_split,
+                       want_bias, ilog2_exact(g->Ho * g->Wo), ilog2_exact(g->Wo));
+    CG_LAUNCH_CHECK("conv_wgrad_x3t_kernel");
+    return CG_OK;
+}
+}  // namespace
+#endif
+// CG_WGRAD_X3_PERM=1 in the environment keeps the v_perm / ds_write_b32 loader (A/B against the transposing LDS read)
+static bool wgrad_x3_use_tr() {
+    static const bool on = CG_X3_INTERLEAVE && getenv("CG_WGRAD_X3_PERM") == nullptr;
+    return on;
+}
+
 extern "C" int cg_conv2d_wgrad_x3_ok(const cg_conv_geom* g) {
     if (!g || g->T < 1 || g->T > CG_MAX_TAPS) return 0;
     const int M = g->N * g->Ho * g->Wo;
@@ -1596,8 +1619,15 @@ extern "C" int cg_conv2d_wgrad_x3(const cg_conv_geom* g, const void* xs, size_t 
     WgradPlan p = plan_wgrad(g);
     float* part = (float*)ws;
     const int want_bias = dbias != nullptr;
+#if CG_X3_INTERLEAVE
+#define WGX(BM_, BN_, WM_, WN_)                                                                                                  \
+    rc = wgrad_x3_use_tr()                                                                                                       \
+             ? launch_wgrad_x3t<BM_, BN_, WM_, WN_>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st) \
+             : launch_wgrad_x3<BM_, BN_, WM_, WN_>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st)
+#else
 #define WGX(BM_, BN_, WM_, WN_) \
     rc = launch_wgrad_x3<BM_, BN_, WM_, WN_>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st)
+#endif
     if (p.bm == 128 && p.bn == 128) WGX(128, 128, 64, 32);   // 8 waves
     else if (p.bm == 128 && p.bn == 64) WGX(128, 64, 64, 32);
     else if (p.bm == 64 && p.bn == 64) WGX(64, 64, 32, 32);
