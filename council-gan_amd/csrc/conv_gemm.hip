@@ -103,6 +103,23 @@ __device__ __forceinline__ bool tap_pixel(const G& g, const RowInfo& ri, int tap
     return ok;
 }
 
+// max |v| of a block's outputs -> state[2 + blockIdx.x] (the slot layout cg_split_f16_dynamic reduces again): lets the
+// convolution that consumes this output in split form skip its own max-reduction pass over the tensor
+template <int NT>
+__device__ __forceinline__ void block_amax_store(float vmax, float* __restrict__ state) {
+    __shared__ float amax_red[NT / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = amax_red[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, amax_red[w]);
+        state[2 + blockIdx.x] = m;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 //   BM x BN block tile, WM x WN wave tile, (BM/WM)*(BN/WN) waves, STAGES LDS buffers.
@@ -112,7 +129,7 @@ __device__ __forceinline__ bool tap_pixel(const G& g, const RowInfo& ri, int tap
 template <int BM, int BN, int WM, int WN, bool FAST, int STAGES>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_kernel(
     cg_conv_geom g, const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ w,
-    const float* __restrict__ bias, float* __restrict__ y, int M, int K, int tiles_n) {
+    const float* __restrict__ bias, float* __restrict__ y, int M, int K, int tiles_n, float* __restrict__ amax_state) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -268,6 +285,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_kernel(
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float vmax = 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn0 + j * 32 + l31;
@@ -279,10 +297,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const RowInfo ri = rows[row];
-                if (ri.base >= 0) y[(size_t)ri.out_off + col] = cg_apply_act(acc[i][j][r] + bj, g.act);
+                if (ri.base >= 0) {
+                    const float v = cg_apply_act(acc[i][j][r] + bj, g.act);
+                    y[(size_t)ri.out_off + col] = v;
+                    vmax = fmaxf(vmax, fabsf(v));
+                }
             }
         }
     }
+    if (amax_state) block_amax_store<NT>(vmax, amax_state);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1145,19 +1168,33 @@ int validate_geom(const cg_conv_geom* g, const char* who) {
     return CG_OK;
 }
 
+// Per-launch option handed from the C entry point to the launcher that ends up running (set and cleared around one call on
+// the calling thread): where the kernel's epilogue should leave its per-block output maxima, and how many it left.
+struct FwdAmax {
+    float* state = nullptr;
+    int nslots = 0;
+};
+static thread_local FwdAmax fwd_amax;
+constexpr int CG_AMAX_SLOTS_MAX = 1024;     // == CG_AMAX_MAX_SLOTS of conv_x3.inc (state[2 .. 2 + 1024))
+
 template <int BM, int BN, int WM, int WN, int STAGES>
 int launch_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias, float* y,
                int M, int K, bool fast, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (g->Cout + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n), block(NT);
+    float* amax = nullptr;
+    if (fwd_amax.state && tiles_m * tiles_n <= CG_AMAX_SLOTS_MAX && g->osy == 1 && g->osx == 1) {
+        amax = fwd_amax.state;
+        fwd_amax.nslots = tiles_m * tiles_n;
+    }
     ProfScope prof(0, BM, BN, fast, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
     if (fast)
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true, STAGES>), grid, block, 0, st, *g, x1, x2, w, bias, y, M,
-                           K, tiles_n);
+                           K, tiles_n, amax);
     else
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false, STAGES>), grid, block, 0, st, *g, x1, x2, w, bias, y,
-                           M, K, tiles_n);
+                           M, K, tiles_n, amax);
     CG_LAUNCH_CHECK("conv_fwd_kernel");
     return CG_OK;
 }
@@ -1399,6 +1436,17 @@ extern "C" int cg_conv2d_fwd(const cg_conv_geom* g, const float* x1, const float
     return conv2d_fwd_impl(g, x1, x2, w, bias, y, -1, stream);
 }
 
+extern "C" int cg_conv2d_fwd_amax(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
+                                  const float* bias, float* y, float* amax_state, int* amax_nslots, cg_stream_t stream) {
+    CG_CHECK_ARG(amax_state && amax_nslots, "cg_conv2d_fwd_amax: null pointer");
+    fwd_amax.state = amax_state;
+    fwd_amax.nslots = 0;
+    const int rc = conv2d_fwd_impl(g, x1, x2, w, bias, y, -1, stream);
+    *amax_nslots = rc ? 0 : fwd_amax.nslots;
+    fwd_amax.state = nullptr;
+    return rc;
+}
+
 extern "C" int cg_conv2d_fwd_stats(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
                                    const float* bias, float* y, double* stats, size_t stats_bytes, int* rows_per_partial,
                                    cg_stream_t stream) {
@@ -1438,8 +1486,11 @@ extern "C" int cg_split_f16(const float* x, void* out, size_t n, size_t lo_elems
 extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_lo_elems, const void* ws,
                                 size_t w_lo_elems, float w_scale, const float* x_scale_dev, const float* bias, float* y,
                                 void* y_split, size_t y_lo_elems, double* stats, size_t stats_bytes,
-                                int* rows_per_partial, int tile_cfg, cg_stream_t stream) {
+                                int* rows_per_partial, int tile_cfg, float* amax_state, int* amax_nslots,
+                                cg_stream_t stream) {
     int rc = validate_geom(g, "cg_conv2d_fwd_x3");
+    CG_CHECK_ARG((amax_state == nullptr) == (amax_nslots == nullptr), "cg_conv2d_fwd_x3: amax_state and amax_nslots go together");
+    if (amax_nslots) *amax_nslots = 0;
     if (rc) return rc;
     CG_CHECK_ARG(xs && ws && y && w_scale > 0.f, "cg_conv2d_fwd_x3: null pointer / bad scale");
     CG_CHECK_ARG(!y_split || x3_lo_ok(y_lo_elems, (size_t)g->N * g->HoF * g->WoF * g->Cout * 2), "cg_conv2d_fwd_x3: bad y lo offset");
@@ -1468,8 +1519,13 @@ extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_
         }
     }
     hipStream_t st = cg_s(stream);
-    return launch_x3_cfg(cfg, b, 1, xs, bias, y, (unsigned)(x_lo_elems * 2), (unsigned)x_span, 1.0f / w_scale, x_scale_dev, st,
-                         st_ptr, y_split, y_lo_elems);
+    fwd_amax.state = amax_state;
+    fwd_amax.nslots = 0;
+    rc = launch_x3_cfg(cfg, b, 1, xs, bias, y, (unsigned)(x_lo_elems * 2), (unsigned)x_span, 1.0f / w_scale, x_scale_dev, st,
+                       st_ptr, y_split, y_lo_elems);
+    if (amax_nslots && !rc) *amax_nslots = fwd_amax.nslots;
+    fwd_amax.state = nullptr;
+    return rc;
 }
 
 extern "C" int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, float* state, int nslots,

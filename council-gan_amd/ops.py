@@ -120,7 +120,7 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x2, weight, bias, wgrad_buf, bgrad_buf, stride, pad, act, up, stats, xsplit=None, wsplit=None,
-                out_split=None):
+                out_split=None, amax_out=None):
         lib = _lib()
         x, x2, w = nhwc(x), nhwc(x2), nhwc(weight)
         N, C1, H, W = x.shape
@@ -144,9 +144,15 @@ class _Conv2d(torch.autograd.Function):
             if out_split is not None:
                 ysp = SplitTensor(torch.empty(2 * y.numel(), dtype=torch.float16, device=y.device), y.shape)
                 out_split.append(ysp)
+            state, nslots = None, None
+            if amax_out is not None and ysp is None:     # the consumer will split y dynamically: hand it the block maxima
+                state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=y.device), ctypes.c_int(0)
             check(lib.cg_conv2d_fwd_x3(byref(g), xsplit.hi_ptr(), xsplit.lo, wsplit.hi_ptr(), wsplit.lo, float(wsplit.scale),
                                        xsplit.scale_ptr(), ptr(bias), ptr(y), ysp.hi_ptr() if ysp else None,
-                                       ysp.lo if ysp else 0, ptr(sws), sbytes, rp, -1, stream()), "cg_conv2d_fwd_x3")
+                                       ysp.lo if ysp else 0, ptr(sws), sbytes, rp, -1, ptr(state),
+                                       byref(nslots) if nslots is not None else None, stream()), "cg_conv2d_fwd_x3")
+            if nslots is not None and nslots.value:
+                amax_out.append((state, nslots.value))
             if stats is not None and rows.value:
                 stats.append((sws, rows.value))
         elif stats is not None and act == 0:
@@ -158,6 +164,12 @@ class _Conv2d(torch.autograd.Function):
                                           byref(rows), stream()), "cg_conv2d_fwd_stats")
             if rows.value:
                 stats.append((sws, rows.value))
+        elif amax_out is not None:
+            state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=y.device), ctypes.c_int(0)
+            check(lib.cg_conv2d_fwd_amax(byref(g), ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), ptr(state), byref(nslots),
+                                         stream()), "cg_conv2d_fwd_amax")
+            if nslots.value:
+                amax_out.append((state, nslots.value))
         else:
             check(lib.cg_conv2d_fwd(byref(g), ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), stream()), "cg_conv2d_fwd")
         ctx.save_for_backward(x, x2, w, y if act else None)
@@ -219,7 +231,7 @@ class _Conv2d(torch.autograd.Function):
         dx2 = None
         if x2 is not None and ctx.needs_input_grad[1]:
             dx2 = dgrad(g, dz_in, w, x.shape[1], x2.shape[1])
-        return dx, dx2, dw, db, None, None, None, None, None, None, None, None, None, None
+        return dx, dx2, dw, db, None, None, None, None, None, None, None, None, None, None, None
 
 
 X3_FORWARD = True     # module switches (Council_Trainer sets them from the config): split-precision forward convolutions,
@@ -247,14 +259,21 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=
         else:
             if xsplit is None:       # arbitrary-scale input (discriminator activations): per-tensor scale on the device
                 with torch.no_grad():
-                    xsplit = split_f16_dynamic(x.detach())
+                    # the convolution that produced x left its per-block maxima behind (amax_out below): no reduction pass
+                    xsplit = split_f16_dynamic(x.detach(), getattr(x, "_cg_amax", None))
             if want_split and stats is None and xsplit.state is None:
                 out_split = []       # O(1) chain (norm -> conv+ReLU -> conv): the epilogue emits the next operand
+    # un-normalised outputs with a multiple of 32 channels may be split dynamically by the next convolution: let this
+    # one's epilogue measure them (stats is None: no instance norm in between)
+    amax_out = [] if (X3_FORWARD and X3_DYNAMIC_INPUT and stats is None and out_split is None and weight.dim() == 4 and
+                      weight.shape[0] % 32 == 0) else None
     y = _Conv2d.apply(x, x2, weight, bias, getattr(weight, "_cg_grad", None),
                       getattr(bias, "_cg_grad", None) if bias is not None else None,
-                      int(stride), int(pad), ACT[act], bool(upsample), stats, xsplit, wsplit, out_split)
+                      int(stride), int(pad), ACT[act], bool(upsample), stats, xsplit, wsplit, out_split, amax_out)
     if out_split:
         y._cg_split = out_split[0]
+    if amax_out:
+        y._cg_amax = amax_out[0]
     return y
 
 
@@ -588,7 +607,7 @@ def conv2d_x3(xs, wsplit, Cout, KH, KW, bias=None, stride=1, pad=0, act="none", 
     if xs.scale != 1.0:
         raise hip.HipError("conv2d_x3: activations carry a static scale of 1 or a device-side one")
     check(lib.cg_conv2d_fwd_x3(byref(g), xs.hi_ptr(), xs.lo, wsplit.hi_ptr(), wsplit.lo, float(wsplit.scale), xs.scale_ptr(),
-                               ptr(bias), ptr(y), None, 0, ptr(sws), sbytes, rp, -1, stream()), "cg_conv2d_fwd_x3")
+                               ptr(bias), ptr(y), None, 0, ptr(sws), sbytes, rp, -1, None, None, stream()), "cg_conv2d_fwd_x3")
     if stats is not None and rows.value:
         stats.append((sws, rows.value))
     return y

@@ -98,7 +98,13 @@ int cg_split_f16(const float* x, void* out, size_t n, size_t lo_elems, float sca
 int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* x_hi, size_t x_lo_elems, const void* w_hi, size_t w_lo_elems,
                      float w_scale, const float* x_scale_dev, const float* bias, float* y, void* y_split,
                      size_t y_lo_elems, double* stats, size_t stats_bytes, int* rows_per_partial, int tile_cfg,
-                     cg_stream_t stream);
+                     float* amax_state, int* amax_nslots, cg_stream_t stream);
+/* amax_state / amax_nslots (both or neither): the epilogue leaves max|y| per block in amax_state[2 .. 2 + *amax_nslots)
+ * (a CG_SPLIT_STATE_FLOATS buffer) for cg_split_f16_dynamic(y, ..., state, nslots), which then skips its own reduction
+ * pass over y; *amax_nslots = 0 when the launch cannot provide them (more than 1024 blocks).  cg_conv2d_fwd_amax is
+ * cg_conv2d_fwd with the same service (the 3/6-channel first layers, whose outputs feed split-precision layers). */
+int cg_conv2d_fwd_amax(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias, float* y,
+                       float* amax_state, int* amax_nslots, cg_stream_t stream);
 /* Tensors of arbitrary magnitude (gradients, un-normalised activations) are split with a per-tensor power-of-two scale
  * chosen ON THE DEVICE: state[0] <- max|x|, state[1] <- scale = 2^(5 - floor(log2 max|x|)) (scaled peak in [32, 64));
  * state[2 .. CG_SPLIT_STATE_FLOATS) is scratch (per-block maxima: no atomics, nothing to zero).  Planes hold scale*x;

@@ -465,7 +465,7 @@ def test_split_precision_forward_every_tile_configuration(cga, cfg):
     with torch.no_grad():
         xs, ws = ops.split_f16(xd), ops.split_f16(wd, hip.X3_WSCALE)
         hip.check(lib.cg_conv2d_fwd_x3(byref(geom), xs.hi_ptr(), xs.lo, ws.hi_ptr(), ws.lo, float(ws.scale), None, hip.ptr(bd),
-                                       hip.ptr(y), None, 0, None, 0, None, cfg, hip.stream()), "cg_conv2d_fwd_x3")
+                                       hip.ptr(y), None, 0, None, 0, None, cfg, None, None, hip.stream()), "cg_conv2d_fwd_x3")
     assert rel(y, ref) < 2e-5, rel(y, ref)
 
 
@@ -522,3 +522,46 @@ def test_device_input_pipeline_matches_reference_transforms(cga):
         pipe(imgs, crop_tl=np.array([[Hs - H + 1, 0]] * N))
     with pytest.raises(ValueError):
         cga.DeviceInput('cuda:0', 100, 64)(imgs)
+
+
+@pytest.mark.parametrize("kind", ["fp32_first_layer", "x3", "x3_too_many_blocks"])
+def test_conv_epilogue_reports_output_maximum(cga, kind):
+    """The per-block max|y| a forward convolution can leave behind for the consumer's dynamic split
+    (cg_conv2d_fwd_amax / the amax arguments of cg_conv2d_fwd_x3): their maximum is exactly max|y|, and a split that
+    uses them produces the same scale and halves as one that measures the tensor itself."""
+    import ctypes
+    from ctypes import byref
+    from council_gan_amd import hip, ops
+    lib = hip.load()
+    torch.manual_seed(9)
+    if kind == "fp32_first_layer":
+        N, H, W, Cin, Cout, K, stride, pad = 2, 64, 64, 3, 64, 4, 2, 1
+    elif kind == "x3":
+        N, H, W, Cin, Cout, K, stride, pad = 2, 32, 32, 64, 128, 4, 2, 1
+    else:
+        N, H, W, Cin, Cout, K, stride, pad = 8, 256, 256, 32, 32, 3, 1, 1       # 8192 blocks of 64 rows: no slots
+    x = cl(torch.randn(N, Cin, H, W).cuda() * 3)
+    w = cl((torch.randn(Cout, Cin, K, K) / np.sqrt(Cin * K * K)).cuda())
+    b = torch.randn(Cout).cuda()
+    g = ops.fwd_geom(N, H, W, Cin, 0, 0, K, K, stride, pad, Cout, ops.ACT["lrelu"])
+    y = torch.empty((N, Cout, g.Ho, g.Wo), device="cuda").contiguous(memory_format=torch.channels_last)
+    state = torch.full((hip.SPLIT_STATE_FLOATS,), -1.0, device="cuda")
+    nslots = ctypes.c_int(-1)
+    with torch.no_grad():
+        if kind == "fp32_first_layer":
+            hip.check(lib.cg_conv2d_fwd_amax(byref(g), hip.ptr(x), None, hip.ptr(w), hip.ptr(b), hip.ptr(y), hip.ptr(state),
+                                             byref(nslots), hip.stream()), "cg_conv2d_fwd_amax")
+        else:
+            xs, ws = ops.split_f16_dynamic(x), ops.split_f16(w, hip.X3_WSCALE)
+            hip.check(lib.cg_conv2d_fwd_x3(byref(g), xs.hi_ptr(), xs.lo, ws.hi_ptr(), ws.lo, float(ws.scale), xs.scale_ptr(),
+                                           hip.ptr(b), hip.ptr(y), None, 0, None, 0, None, -1, hip.ptr(state), byref(nslots),
+                                           hip.stream()), "cg_conv2d_fwd_x3")
+        if kind == "x3_too_many_blocks":
+            assert nslots.value == 0
+            return
+        assert 0 < nslots.value <= 1024
+        assert float(state[2:2 + nslots.value].max()) == float(y.abs().max())
+        assert float(state[2:2 + nslots.value].min()) >= 0.0
+        a = ops.split_f16_dynamic(y, (state, nslots.value))
+        r = ops.split_f16_dynamic(y)
+        assert float(a.state[1]) == float(r.state[1]) and torch.equal(a.buf, r.buf)

@@ -25,7 +25,7 @@ def split(lib, t, scale=1.0):
 
 def run_x3(lib, g, xs, ws, b, y, cfg):
     hip.check(lib.cg_conv2d_fwd_x3(byref(g), hip.ptr(xs), ops.x3_lo(xs.numel() // 2), hip.ptr(ws), ops.x3_lo(ws.numel() // 2), hip.X3_WSCALE, None,
-                                   hip.ptr(b), hip.ptr(y), None, 0, None, 0, None, cfg, hip.stream()), "x3")
+                                   hip.ptr(b), hip.ptr(y), None, 0, None, 0, None, cfg, None, None, hip.stream()), "x3")
 
 
 def main():
