@@ -104,7 +104,9 @@ __device__ __forceinline__ bool tap_pixel(const G& g, const RowInfo& ri, int tap
 }
 
 // max |v| of a block's outputs -> state[2 + blockIdx.x] (the slot layout cg_split_f16_dynamic reduces again): lets the
-// convolution that consumes this output in split form skip its own max-reduction pass over the tensor
+// convolution that consumes this output in split form skip its own max-reduction pass over the tensor.  Launches with
+// more than 1024 blocks fold into 1024 slots with an integer atomic max (non-negative floats order like their bit
+// patterns); the launcher zeroes the slots first.
 template <int NT>
 __device__ __forceinline__ void block_amax_store(float vmax, float* __restrict__ state) {
     __shared__ float amax_red[NT / 64];
@@ -116,7 +118,8 @@ __device__ __forceinline__ void block_amax_store(float vmax, float* __restrict__
         float m = amax_red[0];
 #pragma unroll
         for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, amax_red[w]);
-        state[2 + blockIdx.x] = m;
+        if (gridDim.x <= 1024) state[2 + blockIdx.x] = m;
+        else atomicMax(reinterpret_cast<unsigned*>(state + 2 + (blockIdx.x & 1023)), __float_as_uint(m));
     }
 }
 
@@ -1176,6 +1179,14 @@ struct FwdAmax {
 };
 static thread_local FwdAmax fwd_amax;
 constexpr int CG_AMAX_SLOTS_MAX = 1024;     // == CG_AMAX_MAX_SLOTS of conv_x3.inc (state[2 .. 2 + 1024))
+// slots a launch of `blocks` blocks fills (block_amax_store): one each, or 1024 shared ones that must start at zero
+static int amax_slots_for(long blocks, float* state, hipStream_t st) {
+    if (blocks <= CG_AMAX_SLOTS_MAX) return (int)blocks;
+    static const bool no_atomic = getenv("CG_NO_AMAX_ATOMIC") != nullptr;      // A/B switch
+    if (no_atomic) return 0;
+    (void)hipMemsetAsync(state + 2, 0, CG_AMAX_SLOTS_MAX * sizeof(float), st);
+    return CG_AMAX_SLOTS_MAX;
+}
 
 template <int BM, int BN, int WM, int WN, int STAGES>
 int launch_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias, float* y,
@@ -1184,9 +1195,9 @@ int launch_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const fl
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (g->Cout + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n), block(NT);
     float* amax = nullptr;
-    if (fwd_amax.state && tiles_m * tiles_n <= CG_AMAX_SLOTS_MAX && g->osy == 1 && g->osx == 1) {
-        amax = fwd_amax.state;
-        fwd_amax.nslots = tiles_m * tiles_n;
+    if (fwd_amax.state && g->osy == 1 && g->osx == 1) {
+        fwd_amax.nslots = amax_slots_for((long)tiles_m * tiles_n, fwd_amax.state, st);
+        if (fwd_amax.nslots) amax = fwd_amax.state;
     }
     ProfScope prof(0, BM, BN, fast, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
     if (fast)

@@ -101,7 +101,8 @@ int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* x_hi, size_t x_lo_elems,
                      float* amax_state, int* amax_nslots, cg_stream_t stream);
 /* amax_state / amax_nslots (both or neither): the epilogue leaves max|y| per block in amax_state[2 .. 2 + *amax_nslots)
  * (a CG_SPLIT_STATE_FLOATS buffer) for cg_split_f16_dynamic(y, ..., state, nslots), which then skips its own reduction
- * pass over y; *amax_nslots = 0 when the launch cannot provide them (more than 1024 blocks).  cg_conv2d_fwd_amax is
+ * pass over y (launches with more than 1024 blocks share 1024 slots through an atomic max); *amax_nslots = 0 when the
+ * launch cannot provide them (strided output classes).  cg_conv2d_fwd_amax is
  * cg_conv2d_fwd with the same service (the 3/6-channel first layers, whose outputs feed split-precision layers). */
 int cg_conv2d_fwd_amax(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias, float* y,
                        float* amax_state, int* amax_nslots, cg_stream_t stream);
