@@ -78,13 +78,13 @@ int cg_conv2d_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const
 int cg_conv2d_fwd_stats(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
                         float* y, double* stats, size_t stats_bytes, int* rows_per_partial, cg_stream_t stream);
 
-/* ---- split-precision ("fp16 x 3") forward, for passes WITHOUT a gradient tape ----------
- * cg_split_f16: out[0..n) = f16(scale*x), out[lo_elems..lo_elems+n) = f16(scale*x - hi), round-to-nearest-even.
- * cg_conv2d_fwd_x3: y = act(conv(x) / w_scale + bias) with x and w given as such plane pairs (x: NHWC, w:
- * [Cout][T][C] pre-multiplied by the power of two w_scale), a*b evaluated as ah*bh + ah*bl + al*bh on the fp16 MFMA
- * with fp32 accumulation (22 significand bits: error at the level of the fp32 kernel's accumulation round-off);
- * same geometry, epilogue and optional instance-norm partials as cg_conv2d_fwd_stats.  tile_cfg -1 = heuristic.
- * The lo plane of an operand starts *_lo_elems halves after its hi plane. */
+/* ---- split-precision ("fp16 x 3") convolutions -------------------------------------------
+ * cg_split_f16: every x[i] -> hi = f16(scale*x[i]), lo = f16(scale*x[i] - hi), round-to-nearest-even, stored in the
+ * {hi, lo} layout described below.
+ * cg_conv2d_fwd_x3: y = act(conv(x) / w_scale + bias) with x and w given in that form (x: NHWC, w: [Cout][T][C]
+ * pre-multiplied by the power of two w_scale), a*b evaluated as ah*bh + ah*bl + al*bh on the fp16 MFMA with fp32
+ * accumulation (22 significand bits: error below the fp32 kernel's accumulation round-off); same geometry, epilogue
+ * and optional instance-norm partials as cg_conv2d_fwd_stats.  tile_cfg -1 = heuristic. */
 #define CG_X3_WSCALE 1024.0f
 /* Layout of a {hi, lo} tensor.  The library is built with the halves interleaved per 32 elements: element i (flat
  * physical index; every split tensor has a channel count that is a multiple of 32) has its hi half at
@@ -108,12 +108,13 @@ int cg_conv2d_fwd_amax(const cg_conv_geom* g, const float* x1, const float* x2, 
                        float* amax_state, int* amax_nslots, cg_stream_t stream);
 /* Tensors of arbitrary magnitude (gradients, un-normalised activations) are split with a per-tensor power-of-two scale
  * chosen ON THE DEVICE: state[0] <- max|x|, state[1] <- scale = 2^(5 - floor(log2 max|x|)) (scaled peak in [32, 64));
- * state[2 .. CG_SPLIT_STATE_FLOATS) is scratch (per-block maxima: no atomics, nothing to zero).  Planes hold scale*x;
+ * state[2 .. CG_SPLIT_STATE_FLOATS) is scratch (per-block maxima).  The halves hold scale*x;
  * consumers take `state + 1` as x_scale_dev / dz_scale_dev and undo the scale in their epilogue.  No host sync. */
 #define CG_SPLIT_STATE_FLOATS 1026
 int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, float* state, int nslots,
                          cg_stream_t stream);   /* nslots > 0: a producer kernel already left that many per-block maxima
-                                                   in state[2..] (cg_instnorm_bwd); 0: measure here */
+                                                   in state[2..] (cg_instnorm_bwd, cg_conv2d_fwd_amax, cg_conv2d_fwd_x3);
+                                                   0: measure here */
 /* dz = dy * act'(y) straight into split form (cg_act_bwd + cg_split_f16_dynamic without the fp32 round trip); dz
  * (optional) additionally receives the fp32 values */
 int cg_act_bwd_split(const float* dy, const float* y, size_t n, int act, void* out, size_t lo_elems, float* state,
@@ -122,17 +123,16 @@ int cg_act_bwd_split(const float* dy, const float* y, size_t n, int act, void* o
  * ws: cg_conv2d_dgrad_workspace(g, nci) bytes (holds the re-laid-out, split weights) */
 int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, size_t dz_lo_elems, const float* dz_scale_dev,
                        const float* w, int ci0, int nci, float* dx, void* ws, size_t ws_bytes, cg_stream_t stream);
-/* split-precision weight gradient: cg_conv2d_wgrad with x and dz given as {hi, lo} fp16 planes (+ device-side scales,
+/* split-precision weight gradient: cg_conv2d_wgrad with x and dz given in {hi, lo} form (+ device-side scales,
  * NULL = 1).  cg_conv2d_wgrad_x3_ok(g) != 0 iff the layer qualifies (one source, every k-tile inside one tap,
- * channel counts multiples of 8, power-of-two output plane); workspace as cg_conv2d_wgrad_workspace(g). */
+ * channel counts multiples of 32, power-of-two output plane); workspace as cg_conv2d_wgrad_workspace(g). */
 int cg_conv2d_wgrad_x3_ok(const cg_conv_geom* g);
 int cg_conv2d_wgrad_x3(const cg_conv_geom* g, const void* x_split, size_t x_lo_elems, const float* x_scale_dev,
                        const void* dz_split, size_t dz_lo_elems, const float* dz_scale_dev, float* dw, float* dbias,
                        int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream);
-/* y_split (optional): the output ALSO in split form (hi plane, lo plane y_lo_elems halves later) for a convolution
- * that consumes it next */
+/* y_split of cg_conv2d_fwd_x3 (optional): the output ALSO in {hi, lo} form for a convolution that consumes it next */
 /* instance norm / AdaIN apply that writes the split form of its output (and / or fp32): the producer side of
- * cg_conv2d_fwd_x3.  y may be NULL (split only); y_split hi plane [N*HW*C], lo plane y_lo_elems further on. */
+ * cg_conv2d_fwd_x3.  y may be NULL (split only); y_split holds N*HW*C {hi, lo} pairs in the layout above. */
 int cg_instnorm_apply_split(const float* x, const float* mean, const float* rstd, const float* gamma,
                             const float* beta, int gstride, const float* residual, float* y, void* y_split,
                             size_t y_lo_elems, int N, int HW, int C, int act, cg_stream_t stream);
