@@ -201,3 +201,34 @@ def test_input_oracle_definitions():
     # flip-then-crop == crop-the-mirrored-window-then-flip
     l2 = IO.window_after_flip(3, 11, 5)
     assert np.array_equal(s.numpy(), IO.sample(img, 2, l2, 4, 5).numpy()[:, :, ::-1])
+
+
+@pytest.mark.parametrize("interleaved", [True, False])
+def test_split_tensor_layout_bookkeeping(interleaved, monkeypatch):
+    """Host-side arithmetic of the {hi, lo} layouts (include/council_gan_hip.h, CG_X3_LO_ELEMS): lo offset, byte offset
+    of a sub-tensor, reconstruction -- on host tensors, no kernel involved."""
+    from council_gan_amd import ops
+    monkeypatch.setattr(ops, "_X3_IL", interleaved)
+    n, off = 96, 64
+    vals = torch.arange(off + n, dtype=torch.float32) / 7.0
+    hi = vals.half()
+    lo = (vals - hi.float()).half()
+    buf = torch.zeros(2 * (off + n), dtype=torch.float16)
+    total = off + n
+    if interleaved:
+        g = buf.view(-1, 64)
+        g[:, :32] = hi.view(-1, 32)
+        g[:, 32:] = lo.view(-1, 32)
+        assert ops.x3_lo(total) == 32
+    else:
+        buf[:total] = hi
+        buf[total:] = lo
+        assert ops.x3_lo(total) == total
+    st = ops.SplitTensor(buf, (n,), off=off, lo=ops.x3_lo(total))
+    assert st.hi_ptr().value - buf.data_ptr() == (4 if interleaved else 2) * off
+    rec = st.to_float()
+    want = hi[off:].float() + lo[off:].float()
+    assert torch.equal(rec, want) and float((rec - vals[off:]).abs().max()) <= 2.0 ** -20 * float(vals.max())
+    if interleaved:
+        with pytest.raises(Exception):
+            ops.SplitTensor(buf, (n,), off=8).hi_ptr()          # sub-tensors start on 32-element boundaries
