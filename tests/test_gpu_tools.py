@@ -56,3 +56,29 @@ def test_translate_folder_cli(tmp_path):
     lo, hi = float(ref.min()), float(ref.max())
     want = (((ref - lo) / (hi - lo)).clamp(0, 1) * 255.0 + 0.5).permute(1, 2, 0).to(torch.uint8).cpu().numpy()
     assert np.abs(want.astype(int) - im.astype(int)).max() <= 1
+
+
+def test_train_synthetic_loop_and_resume(tmp_path):
+    """tools/train_synthetic.py: the reference's loop order through the drop-in API (device input tail, three updates,
+    scheduler step, sample strip, checkpoint), then a resumed run continuing the iteration count."""
+    root = os.path.join(os.path.dirname(__file__), "..")
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import train_synthetic as TS
+    cfg = yaml.safe_load(open(os.path.join(root, "configs", "male2female_council_folder.yaml")))
+    cfg['gen'].update(dim=16, mlp_dim=32, n_res=2)
+    cfg['dis'].update(dim=16)
+    cfg['council']['council_size'] = 2
+    cfg['batch_size'] = 2
+    cfg['new_size'] = 72
+    cfg['crop_image_height'] = cfg['crop_image_width'] = 64
+    cfg['council']['council_start_at_iter'] = 0
+    cfg_path = tmp_path / "cfg.yaml"
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    out = tmp_path / "run"
+    assert TS.main(["--config", str(cfg_path), "--output", str(out), "--iterations", "2"]) == 2
+    files = sorted(os.listdir(out / "checkpoints"))
+    assert 'a2b_gen_0_00000002.pt' in files and 'a2b_dis_council_1_00000002.pt' in files and 'optimizer_1.pt' in files
+    strip = np.asarray(Image.open(out / "images" / "sample_00000002.png"))
+    assert strip.ndim == 3 and strip.shape[2] == 3 and strip.shape[0] % 64 == 0 and strip.shape[1] % 64 == 0
+    assert TS.main(["--config", str(cfg_path), "--output", str(out), "--iterations", "1", "--resume"]) == 3
+    assert 'a2b_gen_0_00000003.pt' in os.listdir(out / "checkpoints")
