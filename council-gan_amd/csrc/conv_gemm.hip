@@ -70,6 +70,12 @@ struct PipeClass {
     int32_t M, K, tiles_n, ntiles;
     uint32_t w_bytes;
     int32_t pad_;
+    // grouped launches (one class per council member, conv_fwd_x3_kernel only): when xs is set the class brings its own
+    // activation / bias / output / scale pointers instead of the launch-wide ones
+    const void* xs;
+    const float* bias;
+    float* y;
+    const float* x_scale;
 };
 struct PipeBatch {
     PipeClass c[4];
@@ -1263,6 +1269,10 @@ void fill_class(PipeClass& pc, const cg_conv_geom* g, const float* w) {
     pc.K = g->T * g->C1;
     pc.w_bytes = (unsigned)((size_t)g->Cout * pc.K * sizeof(float));
     pc.pad_ = 0;
+    pc.xs = nullptr;
+    pc.bias = nullptr;
+    pc.y = nullptr;
+    pc.x_scale = nullptr;
 }
 
 #include "conv_x3.inc"
@@ -1537,6 +1547,41 @@ extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_
     if (amax_nslots && !rc) *amax_nslots = fwd_amax.nslots;
     fwd_amax.state = nullptr;
     return rc;
+}
+
+// One launch for the same layer of up to four council members (same geometry, each with its own activations, weights,
+// bias and output): blockIdx.y = member.  Four times the rows per launch -> the large tiles and full waves of CUs the
+// single-member launches cannot use.  No instance-norm partials / split output / maxima yet.
+extern "C" int cg_conv2d_fwd_x3_group(int n, const cg_conv_geom* g, const void* const* x_hi, size_t x_lo_elems,
+                                      const void* const* w_hi, size_t w_lo_elems, float w_scale,
+                                      const float* const* x_scale_dev, const float* const* bias, float* const* y, int tile_cfg,
+                                      cg_stream_t stream) {
+    int rc = validate_geom(g, "cg_conv2d_fwd_x3_group");
+    if (rc) return rc;
+    CG_CHECK_ARG(n >= 1 && n <= 4 && x_hi && w_hi && y && w_scale > 0.f, "cg_conv2d_fwd_x3_group: 1..4 members, non-null tables");
+    const int K = g->T * g->C1;
+    const int M = g->N * g->Ho * g->Wo;
+    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, w_plane = (size_t)g->Cout * K * 2;
+    CG_CHECK_ARG(x3_lo_ok(x_lo_elems, x_plane) && x3_lo_ok(w_lo_elems, w_plane),
+                 "cg_conv2d_fwd_x3_group: lo offset does not match the operand layout (CG_X3_LO_ELEMS)");
+    const size_t x_span = x3_span(x_lo_elems, x_plane), w_span = x3_span(w_lo_elems, w_plane);
+    CG_CHECK_ARG(g->C2 == 0 && g->C1 % BK == 0 && x_span < (size_t)CG_OOB && w_span < (size_t)CG_OOB && g->osy == 1 && g->osx == 1,
+                 "cg_conv2d_fwd_x3_group: needs one source with C %% 32 == 0 and operands spanning < 2 GiB");
+    PipeBatch b;
+    for (int c = 0; c < n; ++c) {
+        CG_CHECK_ARG(x_hi[c] && w_hi[c] && y[c], "cg_conv2d_fwd_x3_group: null pointer for member %d", c);
+        fill_class(b.c[c], g, (const float*)w_hi[c]);
+        b.c[c].w_bytes = (unsigned)(w_lo_elems * 2);
+        b.c[c].pad_ = (int32_t)w_span;
+        b.c[c].xs = x_hi[c];
+        b.c[c].bias = bias ? bias[c] : nullptr;
+        b.c[c].y = y[c];
+        b.c[c].x_scale = x_scale_dev ? x_scale_dev[c] : nullptr;
+    }
+    const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, (long)M * n, g->C1) : tile_cfg;
+    CG_CHECK_ARG((cfg != 6 && cfg != 7) || g->C1 % 64 == 0, "cg_conv2d_fwd_x3_group: tile configuration %d needs C %% 64 == 0", cfg);
+    return launch_x3_cfg(cfg, b, n, x_hi[0], nullptr, y[0], (unsigned)(x_lo_elems * 2), (unsigned)x_span, 1.0f / w_scale, nullptr,
+                         cg_s(stream), nullptr, nullptr, 0);
 }
 
 extern "C" int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, float* state, int nslots,

@@ -42,6 +42,7 @@ _SIGS = {
     "cg_split_f16": (c_int, [_P, _P, c_size_t, c_size_t, c_float, _P]),
     "cg_conv2d_fwd_x3": (c_int, [POINTER(ConvGeom), _P, c_size_t, _P, c_size_t, c_float, _P, _P, _P, _P, c_size_t, _P, c_size_t,
                                  POINTER(c_int), c_int, _P, POINTER(c_int), _P]),
+    "cg_conv2d_fwd_x3_group": (c_int, [c_int, POINTER(ConvGeom), _P, c_size_t, _P, c_size_t, c_float, _P, _P, _P, c_int, _P]),
     "cg_conv2d_fwd_amax": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, POINTER(c_int), _P]),
     "cg_conv2d_wgrad_x3_ok": (c_int, [POINTER(ConvGeom)]),
     "cg_conv2d_wgrad_x3": (c_int, [POINTER(ConvGeom), _P, c_size_t, _P, _P, c_size_t, _P, _P, _P, c_int, _P, c_size_t, _P]),

@@ -99,6 +99,11 @@ int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* x_hi, size_t x_lo_elems,
                      float w_scale, const float* x_scale_dev, const float* bias, float* y, void* y_split,
                      size_t y_lo_elems, double* stats, size_t stats_bytes, int* rows_per_partial, int tile_cfg,
                      float* amax_state, int* amax_nslots, cg_stream_t stream);
+/* The same layer of n <= 4 council members (one geometry; per-member activations, weights, bias, output, optional
+ * device-side scales) as ONE launch -- tables of n pointers.  Experimental (member-batched execution). */
+int cg_conv2d_fwd_x3_group(int n, const cg_conv_geom* g, const void* const* x_hi, size_t x_lo_elems,
+                           const void* const* w_hi, size_t w_lo_elems, float w_scale, const float* const* x_scale_dev,
+                           const float* const* bias, float* const* y, int tile_cfg, cg_stream_t stream);
 /* amax_state / amax_nslots (both or neither): the epilogue leaves max|y| per block in amax_state[2 .. 2 + *amax_nslots)
  * (a CG_SPLIT_STATE_FLOATS buffer) for cg_split_f16_dynamic(y, ..., state, nslots), which then skips its own reduction
  * pass over y (launches with more than 1024 blocks share 1024 slots through an atomic max); *amax_nslots = 0 when the

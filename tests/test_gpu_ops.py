@@ -562,3 +562,37 @@ def test_conv_epilogue_reports_output_maximum(cga, kind):
         a = ops.split_f16_dynamic(y, (state, nslots.value))
         r = ops.split_f16_dynamic(y)
         assert float(a.state[1]) == float(r.state[1]) and torch.equal(a.buf, r.buf)
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_grouped_split_precision_forward_matches_single_launches(cga, n):
+    """cg_conv2d_fwd_x3_group: the same layer of n council members in one launch == n single-member launches, bit for bit."""
+    import ctypes
+    from ctypes import byref, c_void_p
+    from council_gan_amd import hip, ops
+    lib = hip.load()
+    N, H, W, Cin, Cout, K, stride, pad = 2, 32, 32, 64, 128, 3, 1, 1
+    geom = ops.fwd_geom(N, H, W, Cin, 0, 0, K, K, stride, pad, Cout, ops.ACT["relu"])
+    xs, ws, bs, ys, refs = [], [], [], [], []
+    with torch.no_grad():
+        for m in range(n):
+            torch.manual_seed(100 + m)
+            x = cl(torch.randn(N, Cin, H, W).cuda() * (1 + m))
+            w = cl((torch.randn(Cout, Cin, K, K) / np.sqrt(Cin * K * K)).cuda())
+            b = torch.randn(Cout).cuda()
+            xs.append(ops.split_f16_dynamic(x))
+            ws.append(ops.split_f16(w, hip.X3_WSCALE))
+            bs.append(b)
+            ys.append(torch.full((N, Cout, geom.Ho, geom.Wo), float("nan"), device="cuda").contiguous(memory_format=torch.channels_last))
+            ref = torch.empty_like(ys[-1])
+            hip.check(lib.cg_conv2d_fwd_x3(byref(geom), xs[m].hi_ptr(), xs[m].lo, ws[m].hi_ptr(), ws[m].lo, float(ws[m].scale),
+                                           xs[m].scale_ptr(), hip.ptr(b), hip.ptr(ref), None, 0, None, 0, None, -1, None, None,
+                                           hip.stream()), "cg_conv2d_fwd_x3")
+            refs.append(ref)
+        tab = lambda ptrs: (c_void_p * n)(*[p if isinstance(p, c_void_p) else c_void_p(p) for p in ptrs])
+        hip.check(lib.cg_conv2d_fwd_x3_group(n, byref(geom), tab([t.hi_ptr() for t in xs]), xs[0].lo,
+                                             tab([t.hi_ptr() for t in ws]), ws[0].lo, float(ws[0].scale),
+                                             tab([t.scale_ptr() for t in xs]), tab([hip.ptr(b) for b in bs]),
+                                             tab([hip.ptr(y) for y in ys]), -1, hip.stream()), "cg_conv2d_fwd_x3_group")
+    for m in range(n):
+        assert torch.equal(ys[m], refs[m]), m
