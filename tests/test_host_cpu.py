@@ -232,3 +232,32 @@ def test_split_tensor_layout_bookkeeping(interleaved, monkeypatch):
     if interleaved:
         with pytest.raises(Exception):
             ops.SplitTensor(buf, (n,), off=8).hi_ptr()          # sub-tensors start on 32-element boundaries
+
+
+def test_tool_helpers_on_host(tmp_path):
+    """The host-only helpers of tools/translate_folder.py and tools/train_synthetic.py (image loading geometry, strip layout)."""
+    import sys
+    from PIL import Image
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import train_synthetic as TS
+    import translate_folder as TF
+    rng = np.random.RandomState(1)
+    src = rng.randint(0, 256, size=(100, 150, 3)).astype(np.uint8)
+    Image.fromarray(src).save(tmp_path / "wide.png")
+    Image.fromarray(src.transpose(1, 0, 2).copy()).save(tmp_path / "tall.png")
+    for name in ("wide.png", "tall.png"):
+        a = TF.load_image(str(tmp_path / name), 72, 64, 64)          # shorter side -> 72, centre crop 64x64
+        assert a.shape == (64, 64, 3) and a.dtype == np.uint8 and a.flags.writeable
+    same = TF.load_image(str(tmp_path / "wide.png"), None, 100, 150)  # no resize, crop = whole image
+    assert np.array_equal(same, src)
+    with pytest.raises(ValueError):
+        TF.load_image(str(tmp_path / "wide.png"), 32, 64, 64)
+    u8_a, u8_b = TS.synthetic_u8(rng, 3, 16)
+    assert u8_a.shape == u8_b.shape == (3, 16, 16, 3) and u8_a.dtype == np.uint8
+    rows = (torch.full((2, 3, 8, 8), -1.0), None, torch.full((2, 3, 8, 8), 1.0))
+    TS.save_strip(rows, str(tmp_path / "strip.png"))
+    strip = np.asarray(Image.open(tmp_path / "strip.png"))
+    assert strip.shape == (16, 16, 3) and strip[:8].max() == 0 and strip[8:].min() == 255
+    TF.save_normalised(torch.linspace(-3, 5, 3 * 4 * 4).view(1, 3, 4, 4), str(tmp_path / "n.png"))
+    n = np.asarray(Image.open(tmp_path / "n.png"))
+    assert n.shape == (4, 4, 3) and n.min() == 0 and n.max() == 255
