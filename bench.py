@@ -58,6 +58,17 @@ def w_min_tflop(batch, size, council, n_rel):
     return per * sigma * council / 1000.0
 
 
+# BASELINE.json configs[1], [2] (= the metric's configuration, the default), [4] as one flag each
+PRESETS = {
+    2: dict(config="glasses_council_folder.yaml", council=1, batch=8, size=128,
+            name="cfg2: glasses 128x128 council=1 batch=8 (single gen/dis pair, no council step)"),
+    3: dict(config="male2female_council_folder.yaml", council=4, batch=4, size=256,
+            name="cfg3: male2female 256x256 council=4 batch=4 (the metric's configuration)"),
+    5: dict(config="anime2face_council_folder.yaml", council=8, batch=4, size=256,
+            name="cfg5: anime2face 256x256 council=8 batch=4 (at N=1: the denominator of the >= 6x at 8 GPUs target)"),
+}
+
+
 def build_config(args, world):
     cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", args.config)))
     council = args.council if args.council else 4      # more ranks than members: the members' batch is split (parallel.py)
@@ -68,25 +79,43 @@ def build_config(args, world):
     return cfg
 
 
-def cpu_baseline(cfg, tr_state_fn, size, seconds_hint=25.0):
-    """Oracle ("port" of the reference) on the host cores, bounded sample: ONE iteration of the same
-    council / resolution at batch_size 1."""
+def cpu_baseline(cfg, tr_state_fn, size, batch_full, timed=2):
+    """Oracle ("port" of the reference) on the host cores, bounded sample: the same council / resolution at batch_size 1,
+    one warm-up iteration + `timed` timed ones."""
     from oracle import council_oracle as O
     cfg = copy.deepcopy(cfg)
     cfg['batch_size'] = 1
     otr = O.OracleTrainer(cfg, tr_state_fn())
     x_a, x_b = O.synthetic_batch(1, size)
     O.seed_all(1)
+
+    def it():
+        otr.dis_update(x_a, x_b, cfg)
+        otr.dis_council_update(x_a, x_b, cfg)
+        otr.gen_update(x_a, x_b, cfg, cfg['iteration'])
     t0 = time.time()
-    otr.dis_update(x_a, x_b, cfg)
-    otr.dis_council_update(x_a, x_b, cfg)
-    otr.gen_update(x_a, x_b, cfg, cfg['iteration'])
-    dt = time.time() - t0
+    it()
+    warm = time.time() - t0
+    t0 = time.time()
+    for _ in range(timed):
+        it()
+    dt = (time.time() - t0) / timed
     return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/council_oracle.py, 1 cold iteration (dis+dis_council+gen updates, all %d members) of the "
-                      "same %dx%d council=%d workload at batch_size 1 instead of %d; %.1f s of CPU work, %d torch threads"
-                      % (cfg['council']['council_size'], size, size, cfg['council']['council_size'], 0, dt,
-                         torch.get_num_threads())}
+            "sample": "oracle/council_oracle.py at batch_size 1 (the GPU line runs batch_size %d): the same %dx%d council=%d "
+                      "iteration (dis + dis_council + gen updates of all members), 1 warm-up (%.1f s) + %d timed iterations, "
+                      "%.1f s each, %d torch threads"
+                      % (batch_full, size, size, cfg['council']['council_size'], warm, timed, dt, torch.get_num_threads())}
+
+
+def time_steps(step, fence, warmup, steps, first=0):
+    for it in range(warmup):
+        step(first + it)
+    fence()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        step(first + warmup + it)
+    fence()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -94,14 +123,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cfg", type=int, default=0, choices=[0, 2, 3, 5],
+                    help="BASELINE.json configuration preset: 2 = glasses 128^2 council 1 batch 8, 3 = the default, "
+                         "5 = anime2face 256^2 council 8")
     ap.add_argument("--config", default="male2female_council_folder.yaml")
     ap.add_argument("--council", type=int, default=0, help="override council size (default 4)")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32-MFMA sub-record")
     ap.add_argument("--shape-report", default="", help="write the per-layer-shape conv timing table to this file")
     args = ap.parse_args()
+    preset = PRESETS.get(args.cfg)
+    if preset:
+        args.config, args.council, args.batch, args.size = preset["config"], preset["council"], preset["batch"], preset["size"]
 
     import council_gan_amd as cga
     # CG_DIST_BACKEND=gloo + CG_SHARE_GPU=1: several ranks on ONE GPU (smoke test of the N>1 code path on a 1-GPU box)
@@ -133,7 +169,8 @@ def main():
     def step(it):
         cfg['iteration'] = 60000 + it
         trainer.dis_update(x_a, x_b, cfg)
-        trainer.dis_council_update(x_a, x_b, cfg)
+        if council > 1:      # council 1: train.py's call only prints "no council discriminetor is needed" and returns
+            trainer.dis_council_update(x_a, x_b, cfg)
         trainer.gen_update(x_a, x_b, cfg, cfg['iteration'])
 
     def fence():
@@ -141,14 +178,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for it in range(args.warmup):
-        step(it)
-    fence()
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        step(args.warmup + it)
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = time_steps(step, fence, args.warmup, args.steps)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -159,13 +189,24 @@ def main():
     n_rel = cfg['council']['numberOfCouncil_dis_relative_iteration']
     wmin = w_min_tflop(args.batch, args.size, council, n_rel)
     out = {
-        "metric": "training images/sec (gen+dis step), 256x256 council=4, 1/2/4/8 MI355X",
+        "metric": ("training images/sec (gen+dis step), 256x256 council=4, 1/2/4/8 MI355X"
+                   if (args.size == 256 and council == 4) else
+                   "training images/sec (gen+dis step), %dx%d council=%d" % (args.size, args.size, council)),
         "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "strong" if council == 4 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": ("f32 storage/accumulate, fp16x3 split-precision (22-bit) contraction" if trainer._split_fwd else "f32"),
+        "data": "synthetic",
         "config": {"workload": "%s %dx%d council=%d batch=%d: dis_update + dis_council_update + gen_update "
-                               "(train.py:237-251), fp32, all Adam steps" % (args.config.split('_')[0], args.size,
-                                                                               args.size, council, args.batch),
+                               "(train.py:237-251), all Adam steps" % (args.config.split('_')[0], args.size,
+                                                                         args.size, council, args.batch),
+                   "preset": (preset["name"] if preset else
+                              ("cfg3: male2female 256x256 council=4 batch=4 (the metric's configuration)"
+                               if (args.config.startswith("male2female") and council == 4 and args.batch == 4 and args.size == 256)
+                               else "custom")),
+                   "problem_at_n_gpus": ("same problem at every N (strong scaling): N <= council shards the members, "
+                                         "N > council additionally splits every member's batch over N/council replicas; "
+                                         "this run: council %d on %d GPU(s)" % (council, world)),
                    "members_per_gpu": council / world if council < world else council // world,
                    "parallelism": ("%d council member(s) per GPU, one all-gather of generated images per iteration"
                                    % (council // world) if world <= council else
@@ -187,7 +228,10 @@ def main():
         # traffic: HBM bytes per launch of the dominant kernel on its dominant shape (3x3 256->256 @64x64, 70 % of its
         # launches) from rocprofv3 PMC passes -- 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, profiles/r01_conv_pmc_probe.txt;
         # the algorithmic bytes of that shape are 36.0e6 (activations 16.8 + weights 2.4 + output 16.8 MB)
-        roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "traffic": 53.3e6,
+        # traffic: not measured inside this run (PMC counters need rocprofv3 passes of their own); the counter-derived
+        # figure for the dominant kernel lives in profiles/ (r01_x3_pmc_v2.txt: 53.3 MB per launch of the 3x3 256->256
+        # @64x64 batch-4 shape vs 36.0 MB algorithmic)
+        roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                 "step_achieved": round(step_tflops, 2),
                 "step_frac": round(step_tflops / (F16X3_PEAK_TFLOPS if trainer._split_fwd else FP32_MFMA_PEAK_TFLOPS), 4),
                 "step_frac_vs_fp32_mfma_peak": round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -230,10 +274,37 @@ def main():
         else:
             roof.update({"achieved": round(step_tflops, 2), "frac": round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4)})
         out["roofline"] = roof
+        if trainer._split_fwd and not args.no_exact_fp32:
+            # the same workload on the exact-fp32-MFMA datapath (cg_forward_precision: fp32), timed the same way in this
+            # run: the denominator of "faster than exact fp32 could be" and the figure to hold against the 157.3 peak
+            try:
+                cfg32 = copy.deepcopy(cfg)
+                cfg32['cg_forward_precision'] = 'fp32'
+                cga.seed_everything(cfg['random_seed'])
+                tr32 = cga.Council_Trainer(cfg32, str(device))
+                tr32.cuda(device)
+
+                def step32(it):
+                    cfg32['iteration'] = 60000 + it
+                    tr32.dis_update(x_a, x_b, cfg32)
+                    if council > 1:
+                        tr32.dis_council_update(x_a, x_b, cfg32)
+                    tr32.gen_update(x_a, x_b, cfg32, cfg32['iteration'])
+                n32 = max(2, min(args.steps, 6))
+                el32 = time_steps(step32, fence, 2, n32)
+                ms32 = 1000.0 * el32 / n32
+                out["exact_fp32"] = {"value": round(args.batch * n32 / el32, 4), "unit": "images/sec", "ms_per_step": round(ms32, 3),
+                                     "steps": n32, "warmup": 2, "dtype": "f32 (v_mfma_f32_32x32x2_f32 everywhere)",
+                                     "step_achieved": round(wmin / (ms32 / 1000.0), 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                                     "step_frac": round(wmin / (ms32 / 1000.0) / FP32_MFMA_PEAK_TFLOPS, 4)}
+                del tr32
+            except Exception as e:      # noqa: BLE001
+                out["exact_fp32"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+            finally:
+                trainer._ready()        # hand the ops-level precision switches back to the benchmarked trainer
         if state_fn is not None:
             try:
-                cb = cpu_baseline(cfg, state_fn, args.size)
-                cb["sample"] = cb["sample"].replace("instead of 0", "instead of %d" % args.batch)
+                cb = cpu_baseline(cfg, state_fn, args.size, args.batch)
             except Exception as e:      # noqa: BLE001 -- the GPU measurement above stands on its own
                 cb = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
                       "sample": "cpu baseline leg failed: %s: %s" % (type(e).__name__, e)}

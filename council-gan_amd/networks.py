@@ -131,8 +131,10 @@ class Conv2dBlock(nn.Module):
 def _split_ok(block):
     """A Conv2dBlock the split-precision path can run: instance-norm / AdaIN after a conv whose input width is a
     multiple of 32, with its weight registered in a split-weight table (Council_Trainer refreshes it)."""
+    co = block.conv.out_channels
     return (getattr(block, '_cg_wsplit', None) is not None and block.norm_type in ('in', 'adain')
-            and block.conv.in_channels % 32 == 0 and block.conv.out_channels % 4 == 0)
+            and block.conv.in_channels % 32 == 0
+            and co % 32 == 0 and 256 % (co // 4) == 0)      # cg_instnorm_apply_split's channel-quad layout
 
 
 def conv_block_split(block, xs, upsample=False, residual=None, want_f32=False):

@@ -182,9 +182,10 @@ class Council_Trainer(nn.Module):
         self._img_cache = {}
         self._enc_cache = {}
         self._streams = []
-        # precision of the FORWARD convolutions (every backward kernel is exact fp32 MFMA): "split" = fp16 x 3 MFMA on
-        # {hi, lo} fp16 operand planes (22 significand bits -- error below the fp32 kernel's accumulation round-off --
-        # at 2.5-2.8x its rate), "fp32" = fp32 MFMA everywhere
+        # datapath of the convolutions with >= 32 channels -- forward, data-gradient and weight-gradient, generators and
+        # both discriminators: "split" = fp16 x 3 MFMA on {hi, lo} fp16 operand planes (22 significand bits -- error
+        # below the fp32 kernel's accumulation round-off -- at 2.5-2.8x its rate; fp32 storage and accumulation),
+        # "fp32" = exact fp32 MFMA everywhere.  The 3/6-channel first layers and the <= 32-channel heads are always fp32.
         self._split_fwd = str(hp.get('cg_forward_precision', os.environ.get('CG_FORWARD_PRECISION', 'split'))) == 'split'
 
     # ------------------------------------------------------------------------------------
@@ -214,12 +215,9 @@ class Council_Trainer(nn.Module):
                                torch.ones(1, device=dev))
                            for i in self.shard.local} for d in self._dirs}
         self._device = dev
-        # Council members are independent models: each local member's kernels go to its own HIP stream, so the
-        # low-occupancy launches of one member (16x16 / 8x8 discriminator layers, 1-block-per-CU convs) overlap with
-        # another member's work.  CG_MEMBER_STREAMS=1 serialises everything on the caller's stream.
-        # split-precision forward convolutions in the GENERATORS (instance-normalised activations: inside fp16's
-        # accurate range by construction; the un-normalised discriminators stay on fp32 MFMA): one lazily refreshed
-        # {hi, lo} fp16 copy of the generator optimizer's weights
+        # split-precision datapath: one lazily refreshed {hi, lo} fp16 copy of every optimizer's flat weight buffer
+        # (generators: instance-normalised activations travel unscaled; discriminators and all gradients: per-tensor
+        # power-of-two scales chosen on the device)
         ops.X3_FORWARD = ops.X3_BACKWARD = ops.X3_DYNAMIC_INPUT = self._split_fwd
         if self._split_fwd:
             for i in self.shard.local:
@@ -233,6 +231,9 @@ class Council_Trainer(nn.Module):
                         # a checkpoint load rewrites the weights behind the optimizer's back: invalidate the copies
                         net.register_load_state_dict_post_hook(
                             lambda module, keys, _opt=opt: setattr(_opt, 'version', _opt.version + 1))
+        # Council members are independent models: each local member's kernels go to its own HIP stream, so the
+        # low-occupancy launches of one member (16x16 / 8x8 discriminator layers, 1-block-per-CU convs) overlap with
+        # another member's work.  CG_MEMBER_STREAMS=1 serialises everything on the caller's stream.
         n = min(int(os.environ.get('CG_MEMBER_STREAMS', '2')), len(self.shard.local))
         self._streams = [torch.cuda.Stream(device=dev) for _ in range(n)] if n > 1 else []
         return self
@@ -261,6 +262,9 @@ class Council_Trainer(nn.Module):
     def _ready(self):
         if self._device is None:
             self.cuda(self.cuda_device)
+        # the datapath choice belongs to THIS trainer: the ops-level switches are re-applied on entry of every compute
+        # method, so trainers with different `cg_forward_precision` can alternate inside one process
+        ops.X3_FORWARD = ops.X3_BACKWARD = ops.X3_DYNAMIC_INPUT = self._split_fwd
 
     def _img(self, x, slot=None):
         """Device / NHWC copy of a caller tensor.  The copy is re-used while the caller passes the very same
@@ -610,10 +614,14 @@ class Council_Trainer(nn.Module):
     # ------------------------------------------------------------------------------------
     @torch.no_grad()
     def sample(self, x_a=None, x_b=None, s_a=None, s_b=None, council_member_to_sample_vec=None, return_mask=True):
+        """trainer_council.py:643-733: the 8-tuple (x_a_s, masks | reconstructions, x_ab1, x_ab2, x_b_s, ..., x_ba1, x_ba2),
+        rows ordered (image n, member j).  With the council sharded over several ranks every rank renders its own
+        members and one all-gather per output completes the strips, so every rank returns the reference's layout."""
         self._ready()
         self.eval()
         out = {}
-        members = range(self.council_size) if council_member_to_sample_vec is None else council_member_to_sample_vec
+        members = list(range(self.council_size) if council_member_to_sample_vec is None else council_member_to_sample_vec)
+        sharded = self.shard.world_size > 1
         for d, xin, s_fixed in (('a2b', x_a, s_b if s_b is not None else self.s_b),
                                 ('b2a', x_b, s_a if s_a is not None else self.s_a)):
             if d not in self._dirs:
@@ -621,25 +629,29 @@ class Council_Trainer(nn.Module):
             xin = self._img(xin)
             s1 = s_fixed.to(self._device)
             s2 = self._noise(xin.size(0)).to(self._device)
-            xs, recon, x1, x2, masks = [], [], [], [], []
-            for n in range(xin.size(0)):
-                for j in members:
-                    if j not in self.shard.local:
-                        continue
-                    gen = self._nets('gen', d)[j]
+            per = {}                                   # member -> (second, x1, x2), each [n images, C, H, W]
+            for j in (self.shard.local if sharded else members):
+                gen = self._nets('gen', d)[j]
+                second, x1, x2 = [], [], []
+                for n in range(xin.size(0)):
                     xi = xin[n:n + 1]
-                    xs.append(xi)
                     if not return_mask:
                         content, s_fake = gen.encode(xi)
-                        recon.append(gen.decode(content, s_fake, xi))
+                        second.append(gen.decode(content, s_fake, xi))
                         x1.append(gen.decode(content, s1[n:n + 1], xi))
                     else:
-                        content = gen.encode_content(xi)
+                        content = gen.encode_content(xi)       # the style code (:671) is not used on this branch
                         im, m = gen.decode(content, s1[n:n + 1], xi, return_mask=True)
                         x1.append(im)
-                        masks.append(m)
+                        second.append(m)
                     x2.append(gen.decode(content, s2[n:n + 1], xi))
-            out[d] = (torch.cat(xs), torch.cat(masks) if return_mask else torch.cat(recon), torch.cat(x1), torch.cat(x2))
+                per[j] = (torch.cat(second), torch.cat(x1), torch.cat(x2))
+            if sharded:
+                full = [self.shard.exchange([per[j][k] for j in self.shard.local]) for k in range(3)]
+                per = {j: tuple(full[k][j] for k in range(3)) for j in members}
+            rows = [(n, j) for n in range(xin.size(0)) for j in members]
+            out[d] = (torch.cat([xin[n:n + 1] for n, _ in rows]),) + tuple(
+                torch.cat([per[j][k][n:n + 1] for n, j in rows]) for k in range(3))
         self.train()
         none4 = (None, None, None, None)
         return out.get('a2b', none4) + out.get('b2a', none4)
@@ -663,6 +675,9 @@ class Council_Trainer(nn.Module):
                 for i in self.shard.local:
                     gen = self._nets('gen', d)[i]
                     res[d].append(gen.decode(gen.encode_content(xin), sd, xin))
+                if self.shard.world_size > 1:          # every rank returns every member's translation
+                    full = self.shard.exchange(res[d])
+                    res[d] = [full[i] for i in range(self.council_size)]
         if self.do_a2b_conf and self.do_b2a_conf:
             return res['a2b'], res['b2a']
         return res['b2a'] if self.do_b2a_conf else res['a2b']
@@ -677,17 +692,40 @@ class Council_Trainer(nn.Module):
     # checkpoints, trainer_council.py:898-992 (file names / dict keys / tensor shapes unchanged;
     # each rank writes and reads the files of its own members)
     # ------------------------------------------------------------------------------------
+    def _io_device(self):
+        """Device the checkpoint tensors live on.  save() / resume() are file I/O, not compute: they also work on a
+        trainer that was never moved to a GPU (checkpoint conversion / inspection on a host; the optimizers' flat buffers
+        are then laid out in host memory and move with a later .cuda())."""
+        if self._device is not None:
+            return self._device
+        if torch.cuda.is_available():
+            self._ready()
+            return self._device
+        for i in self.shard.local:
+            for opt in (self.gen_opt_s[i], self.dis_opt_s[i]) + ((self.dis_council_opt_s[i],) if self.do_dis_council else ()):
+                opt.materialize('cpu')
+        return torch.device('cpu')
+
+    @staticmethod
+    def _plain_state(net):
+        """state_dict with independent, contiguous (OIHW) tensors: the parameters are channels_last VIEWS into the
+        optimizer's flat buffer, and torch.save would serialise that whole buffer once per file."""
+        sd = net.state_dict()
+        for k in list(sd):
+            sd[k] = sd[k].detach().clone(memory_format=torch.contiguous_format)
+        return sd
+
     def save(self, snapshot_dir, iterations):
-        self._ready()
+        self._io_device()
         if self.shard.slice_idx != 0:      # replicas of a member hold identical weights: the first one writes
             return
         for i in self.shard.local:
             tag = '_%d_%08d.pt' % (i, iterations + 1)
             for d in self._dirs:
-                torch.save({d: self._nets('gen', d)[i].state_dict()}, os.path.join(snapshot_dir, d + '_gen' + tag))
-                torch.save({d: self._nets('dis', d)[i].state_dict()}, os.path.join(snapshot_dir, d + '_dis' + tag))
+                torch.save({d: self._plain_state(self._nets('gen', d)[i])}, os.path.join(snapshot_dir, d + '_gen' + tag))
+                torch.save({d: self._plain_state(self._nets('dis', d)[i])}, os.path.join(snapshot_dir, d + '_dis' + tag))
                 if self.do_dis_council:
-                    torch.save({d: self._nets('disc', d)[i].state_dict()},
+                    torch.save({d: self._plain_state(self._nets('disc', d)[i])},
                                os.path.join(snapshot_dir, d + '_dis_council' + tag))
             opt = {'gen': self.gen_opt_s[i].state_dict(), 'dis': self.dis_opt_s[i].state_dict()}
             if self.do_dis_council:
@@ -695,9 +733,8 @@ class Council_Trainer(nn.Module):
             torch.save(opt, os.path.join(snapshot_dir, 'optimizer_%d.pt' % i))
 
     def resume(self, checkpoint_dir, hyperparameters):
-        self._ready()
+        dev = self._io_device()
         iterations = 0
-        dev = self._device
         for i in self.shard.local:
             for kind, key in (('gen', 'gen_%d' % i), ('dis', 'dis_%d' % i)) + \
                     ((('disc', 'dis_council_%d' % i),) if self.do_dis_council else ()):

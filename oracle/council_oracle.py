@@ -576,6 +576,67 @@ class OracleTrainer:
             self.gen_opt[i].step()
 
 
+    # -- sample, trainer_council.py:643-733 ---------------------------------------------
+    @torch.no_grad()
+    def sample(self, x_a, x_b, s_a_fixed, s_b_fixed, members=None, return_mask=True):
+        """The reference's 8-tuple: per direction (inputs repeated per member, masks | reconstructions, translation with
+        the fixed display style, translation with a fresh style).  Fresh styles: s_b2 then s_a2 (:648, :654)."""
+        members = range(self.C) if members is None else members
+        fresh = {}
+        if 'a2b' in self.dirs:
+            fresh['a2b'] = torch.randn(x_a.size(0), self.style_dim, 1, 1).to(self.dtype)
+        if 'b2a' in self.dirs:
+            fresh['b2a'] = torch.randn(x_b.size(0), self.style_dim, 1, 1).to(self.dtype)
+        out = {}
+        for d, xin, s1 in (('a2b', x_a, s_b_fixed), ('b2a', x_b, s_a_fixed)):
+            if d not in self.dirs:
+                continue
+            xin, s1 = xin.to(self.dtype), s1.to(self.dtype)
+            xs, second, x1, x2 = [], [], [], []
+            for n in range(xin.size(0)):
+                for j in members:
+                    g = self.gen(d, j)
+                    xi = xin[n:n + 1]
+                    xs.append(xi)
+                    c, s_fake = g.encode(xi)                                    # :660, :671
+                    if not return_mask:
+                        second.append(g.decode(c, s_fake, xi))                  # :662, :673
+                        x1.append(g.decode(c, s1[n:n + 1], xi))
+                    else:
+                        im, m = g.decode(c, s1[n:n + 1], xi, return_mask=True)  # :666, :677
+                        x1.append(im)
+                        second.append(m)
+                    x2.append(g.decode(c, fresh[d][n:n + 1], xi))
+            out[d] = (torch.cat(xs), torch.cat(second), torch.cat(x1), torch.cat(x2))
+        none4 = (None, None, None, None)
+        return out.get('a2b', none4) + out.get('b2a', none4)
+
+    # -- resume, trainer_council.py:898-967 ----------------------------------------------
+    def resume(self, checkpoint_dir):
+        """Weights and Adam state from a checkpoint set in the reference's layout (`{d}_{gen|dis|dis_council}_{i}_{it:08d}.pt`
+        holding {d: state_dict}, `optimizer_{i}.pt` holding {'gen','dis','dis_council'}); returns the iteration."""
+        import os
+        names = {'gen': 'gen', 'dis': 'dis', 'dis_council': 'dis_council'}
+        iterations = 0
+        for i in range(self.C):
+            for net in ('gen', 'dis') + (('dis_council',) if self.do_dis_council else ()):
+                for d in self.dirs:
+                    key = '%s_%s_%d_' % (d, names[net], i)
+                    files = sorted(f for f in os.listdir(checkpoint_dir) if f.startswith(key) and f.endswith('.pt'))
+                    sd = torch.load(os.path.join(checkpoint_dir, files[-1]), map_location='cpu')[d]
+                    with torch.no_grad():
+                        for k, t in self.sd[d][net][i].items():
+                            t.copy_(sd[k].to(self.dtype))
+                    if net == 'gen':
+                        iterations = int(files[-1][-11:-3])
+            osd = torch.load(os.path.join(checkpoint_dir, 'optimizer_%d.pt' % i), map_location='cpu')
+            self.gen_opt[i].load_state_dict(osd['gen'])
+            self.dis_opt[i].load_state_dict(osd['dis'])
+            if self.do_dis_council:
+                self.disc_opt[i].load_state_dict(osd['dis_council'])
+        return iterations
+
+
 # --------------------------------------------------------------------------------------
 # small utilities shared by tests / bench
 # --------------------------------------------------------------------------------------

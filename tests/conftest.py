@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver's GPU tier)")
+    config.addinivalue_line("markers", "slow: GPU test that also runs minutes of CPU oracle work (`-m 'gpu and not slow'` skips it)")
 
 
 def pytest_collection_modifyitems(config, items):

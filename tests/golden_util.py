@@ -8,8 +8,16 @@ import numpy as np
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def case_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+CKPT_CASES = ("ckpt_c2",)       # fixtures built around a reference-written checkpoint set (oracle/make_golden.py CKPT)
+
+
+def case_names(kind="train"):
+    """Fixture names.  "train": the two-iteration training cases (including the full-width one, whose initial weights
+    are re-derived from the seed); "ckpt": the reference-checkpoint cases; "all": both."""
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    if kind == "all":
+        return names
+    return [n for n in names if (n in CKPT_CASES) == (kind == "ckpt")]
 
 
 class Golden:
@@ -31,14 +39,44 @@ class Golden:
         """All arrays under `prefix` as {suffix: array}."""
         return {k[len(prefix):]: self.z[k] for k in self.z.files if k.startswith(prefix)}
 
+    @property
+    def from_seed(self):
+        return "init_from_seed" in self.z.files
+
     def init_state(self):
-        """{'a2b': {'gen': [sd, ...], 'dis': [...], 'dis_council': [...]}, ...}"""
+        """{'a2b': {'gen': [sd, ...], 'dis': [...], 'dis_council': [...]}, ...}.  Full-width fixtures do not store their
+        initial weights: the HIP trainer's host-side constructor under the reference's seeds (train.py:55-62) reproduces
+        them bit for bit (tests/test_host_cpu.py::test_trainer_init_matches_reference); the per-tensor summary stored
+        in the fixture guards that assumption."""
+        if self.from_seed:
+            return self._seeded_state()
         st = {}
         for d in self.dirs:
             st[d] = {}
             for net in self.nets:
                 st[d][net] = [self.sub("init/%s/%s/%d/" % (d, net, i)) for i in range(self.C)]
         return st
+
+
+def _seeded(self):
+    import copy
+    import council_gan_amd as cga
+    cga.seed_everything(int(self.z["init_from_seed"]))
+    tr = cga.Council_Trainer(copy.deepcopy(self.cfg), 'cuda:0')          # host-side construction only: no GPU involved
+    attr = {"gen": "gen_%s_s", "dis": "dis_%s_s", "dis_council": "dis_council_%s_s"}
+    st = {}
+    for d in self.dirs:
+        st[d] = {}
+        for net in self.nets:
+            st[d][net] = [{k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+                          for m in getattr(tr, attr[net] % d)]
+            for i, sd in enumerate(st[d][net]):
+                ref = self.z["initsum/%s/%s/%d" % (d, net, i)]
+                assert np.array_equal(summary(sd), ref), "seeded initial weights differ from the reference's (%s %s %d)" % (d, net, i)
+    return st
+
+
+Golden._seeded_state = _seeded
 
 
 def summary(d):

@@ -172,16 +172,22 @@ def test_two_iterations_vs_reference(cga, name):
         # ---- losses -------------------------------------------------------------------------
         def lossvec(v):
             return np.array([float(t.detach()) if torch.is_tensor(t) else float(t) for t in v])
-        np.testing.assert_allclose(lossvec(tr.loss_dis_total_s), g[pre + "dis/loss_total"], rtol=ACT_TOL)
+        # Full-width fixture, SECOND iteration: Adam's first step moved all 17 M generator weights by +-lr, including
+        # those whose gradient is round-off noise, and the oracle itself (same ATen as the reference) is then off the
+        # reference by up to 2e-4 in the losses, 5e-4 in discriminator gradients and 4-8e-2 in generator gradient norms
+        # (tests/test_oracle_golden.py): iteration 0 is the strict pin, iteration 1 a 2e-3 / 5e-3 consistency check.
+        chaotic = g.from_seed and it > 0
+        LT = 2e-3 if chaotic else ACT_TOL
+        np.testing.assert_allclose(lossvec(tr.loss_dis_total_s), g[pre + "dis/loss_total"], rtol=LT)
         if (pre + "disc/loss_total") in g:
-            np.testing.assert_allclose(lossvec(tr.loss_dis_council_total_s), g[pre + "disc/loss_total"], rtol=ACT_TOL)
-        np.testing.assert_allclose(lossvec(tr.loss_gen_total_s), g[pre + "gen/loss_total"], rtol=ACT_TOL)
+            np.testing.assert_allclose(lossvec(tr.loss_dis_council_total_s), g[pre + "disc/loss_total"], rtol=LT)
+        np.testing.assert_allclose(lossvec(tr.loss_gen_total_s), g[pre + "gen/loss_total"], rtol=LT)
         for d in g.dirs:
             ab = 'ab' if d == 'a2b' else 'ba'
             np.testing.assert_allclose(lossvec(getattr(tr, 'loss_gen_adv_%s_s' % d)), g[pre + "gen/loss_adv_%s" % d],
-                                       rtol=ACT_TOL)
+                                       rtol=LT)
             np.testing.assert_allclose(lossvec(getattr(tr, 'council_loss_%s_s' % ab)),
-                                       g[pre + "gen/council_loss_%s" % d], rtol=ACT_TOL, atol=1e-7)
+                                       g[pre + "gen/council_loss_%s" % d], rtol=LT, atol=1e-7)
             for nm, attr in (("mask_zero_one", "loss_gen_mask_zero_one_%s_s"), ("mask_total", "loss_gen_mask_total_%s_s"),
                              ("mask_tv", "loss_gen_mask_TV_%s_s")):
                 ref = g[pre + "gen/%s_%s" % (nm, d)]
@@ -193,10 +199,10 @@ def test_two_iterations_vs_reference(cga, name):
                     # value is off its fp64 value by more than 1e-3 on some fixtures, so this criterion is judged
                     # like the generator gradients -- distance to the fp64 oracle, at most twice the reference's
                     r64 = lossvec(otr64.loss_mask_zero_one[d])
-                    tol = np.maximum(ACT_TOL * np.abs(r64), 2 * np.abs(ref - r64)) + 1e-7
+                    tol = np.maximum(LT * np.abs(r64), 2 * np.abs(ref - r64)) + 1e-7
                     assert np.all(np.abs(mine - r64) <= tol), (nm, d, mine, ref, r64)
                 else:
-                    np.testing.assert_allclose(mine, ref, rtol=ACT_TOL, atol=1e-7)
+                    np.testing.assert_allclose(mine, ref, rtol=LT, atol=1e-7)
 
         # ---- gradients and post-step weights --------------------------------------------------
         for (kind, d, i), (gs, ws) in got.items():
@@ -207,11 +213,17 @@ def test_two_iterations_vs_reference(cga, name):
             mine = summary(gs)
             if kind != "gen":
                 # discriminators: clean fp32 gradients
-                bad = np.abs(mine[:, 1] - ref_sum[:, 1]) > ACT_TOL * ref_sum[:, 1] + 1e-5 * scale
+                bad = np.abs(mine[:, 1] - ref_sum[:, 1]) > (5e-3 if chaotic else ACT_TOL) * ref_sum[:, 1] + 1e-5 * scale
+                assert not bad.any(), (kind, d, i, mine[bad], ref_sum[bad])
+            elif g.from_seed and it == 0:
+                # full-width generator: every tensor's gradient norm against the reference's (the 17 M-element tensors
+                # are not stored whole); the reference's own fp32 noise is 2-4e-3
+                bad = np.abs(mine[:, 1] - ref_sum[:, 1]) > 1e-2 * ref_sum[:, 1] + 1e-4 * scale
                 assert not bad.any(), (kind, d, i, mine[bad], ref_sum[bad])
             ref_full = g.sub(pre + "%s/grad/%s/%d/" % (kind, d, i))
             if ref_full:
-                r64 = g64[(kind, d, i)]
+                # (a full-width fixture stores only the tensors with <= 16384 elements whole)
+                r64 = {k: v for k, v in g64[(kind, d, i)].items() if k in ref_full}
                 e_ref = l2rel(ref_full, r64)
                 e_ours = l2rel({k: gs[k] for k in r64}, r64)
                 report[(it, kind, d, i)] = (e_ours, e_ref)
@@ -237,47 +249,17 @@ def test_two_iterations_vs_reference(cga, name):
 
 
 def test_full_width_iteration_vs_oracle(cga):
-    """Real channel widths (gen dim 64 / dis dim 64, every FAST tile path) at 64x64, batch 2, council 2:
-    one full iteration against the fp32 oracle built from the trainer's own seeded weights."""
+    """Real channel widths (gen dim 64 / dis dim 64, every FAST tile path) at 64x64, batch 2, council 2: one full
+    iteration against the oracle built from the trainer's own seeded weights -- losses and discriminator gradients
+    <= 1e-3, generator gradients within twice the fp32 oracle's own distance to its fp64 twin, post-step weights
+    (criteria: tests/parity_util.py)."""
     import os
     import yaml
+    import parity_util as P
     cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "configs", "male2female_council_folder.yaml")))
     cfg['council']['council_size'] = 2
-    cfg['batch_size'] = 2
     cfg['iteration'] = 60000
-    O.seed_all(1)
-    tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
-    state = {'a2b': {'gen': [O.to_numpy_state(m.state_dict()) for m in tr.gen_a2b_s],
-                     'dis': [O.to_numpy_state(m.state_dict()) for m in tr.dis_a2b_s],
-                     'dis_council': [O.to_numpy_state(m.state_dict()) for m in tr.dis_council_a2b_s]}}
-    tr.cuda('cuda:0')
-    otr = O.OracleTrainer(copy.deepcopy(cfg), state)
-    x_a, x_b = O.synthetic_batch(2, 64)
-    st_r, st_t = random.getstate(), torch.get_rng_state()
-    tr.dis_update(x_a, x_b, cfg); tr.dis_council_update(x_a, x_b, cfg); tr.gen_update(x_a, x_b, cfg, 60000)
-    random.setstate(st_r); torch.set_rng_state(st_t)
-    ref = {}
-
-    def snap(kind, onet):
-        for i in range(2):
-            ref[(kind, i)] = {k: t.grad.numpy().copy() for k, t in otr.sd['a2b'][onet][i].items()
-                              if t.requires_grad and t.grad is not None}
-    otr.dis_update(x_a, x_b, cfg); snap("dis", "dis")
-    otr.dis_council_update(x_a, x_b, cfg); snap("disc", "dis_council")
-    otr.gen_update(x_a, x_b, cfg, 60000); snap("gen", "gen")
-    f = lambda v: np.array([float(t.detach()) for t in v])
-    np.testing.assert_allclose(f(tr.loss_dis_total_s), f(otr.loss_dis_total), rtol=ACT_TOL)
-    np.testing.assert_allclose(f(tr.loss_dis_council_total_s), f(otr.loss_disc_total), rtol=ACT_TOL)
-    np.testing.assert_allclose(f(tr.loss_gen_total_s), f(otr.loss_gen_total), rtol=ACT_TOL)
-    errs = {}
-    for i in range(2):
-        for kind, attr in (("dis", tr.dis_a2b_s), ("disc", tr.dis_council_a2b_s), ("gen", tr.gen_a2b_s)):
-            gs = grads_of(attr[i])
-            assert set(gs) == set(ref[(kind, i)]), (kind, set(gs) ^ set(ref[(kind, i)]))
-            errs[(kind, i)] = l2rel(gs, ref[(kind, i)])
-    print("\n[full-width grad l2-rel vs fp32 oracle]", {k: "%.2e" % v for k, v in errs.items()})
-    for (kind, i), e in errs.items():
-        assert e < (1e-2 if kind == "gen" else ACT_TOL), (kind, i, e)
+    P.iteration_vs_oracle(cga, cfg, 64, 2, seed=1, report="full width 64^2 council 2 B2")
 
 
 def test_content_cache_is_invalidated(cga):

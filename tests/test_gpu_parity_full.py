@@ -1,0 +1,232 @@
+"""Whole-iteration parity of the BENCHMARKED datapath (fp16x3 split-precision contractions, fp32 storage / accumulation)
+against the oracle at the shapes BASELINE.json names, at full network widths:
+
+  * configs[2] -- male2female 256x256, council 4 (batch 1: the oracle needs ~30 s + the fp64 twin at this size);
+  * configs[1] -- glasses 128x128, council 1 (batch 2), a whole single-member step with no council term
+    (trainer_council.py:784-786 early-out);
+  * configs[4]'s family -- anime2face (b2a direction, 3-channel mask head) at 128x128, council 2.
+
+Criteria: tests/parity_util.py.  Plus the reference-pinned parts of SURVEY.md 8f on the GPU: sample() against the
+reference's recorded 8-tuple, resume() from a reference-written checkpoint set."""
+import copy
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import parity_util as P
+from golden_util import Golden, case_names, rel_err, summary
+from oracle import council_oracle as O
+
+pytestmark = pytest.mark.gpu
+CONFIGS = os.path.join(os.path.dirname(__file__), "..", "configs")
+
+
+@pytest.fixture(scope="module")
+def cga():
+    import council_gan_amd
+    council_gan_amd.hip.load()
+    return council_gan_amd
+
+
+_orig_randn, _orig_choice = torch.randn, random.choice
+
+
+@pytest.fixture(autouse=True)
+def _restore_rng_functions():
+    yield
+    torch.randn, random.choice = _orig_randn, _orig_choice
+
+
+def _cfg(name, council, iteration=60000):
+    cfg = yaml.safe_load(open(os.path.join(CONFIGS, name)))
+    cfg['council']['council_size'] = council
+    cfg['iteration'] = iteration
+    return cfg
+
+
+@pytest.mark.slow
+def test_bench_shape_iteration_vs_oracle(cga):
+    """BASELINE.json configs[2] / bench.py's default workload at batch 1: every x3 / pipelined tile configuration the
+    bench uses at 256x256 with 64..512 channels, all four members, council + focus losses live."""
+    cfg = _cfg("male2female_council_folder.yaml", 4)
+    tr_probe = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+    assert tr_probe._split_fwd, "the benchmarked datapath is the split-precision one"
+    del tr_probe
+    P.iteration_vs_oracle(cga, cfg, 256, 1, seed=1, report="cfg3 256^2 council 4 B1")
+
+
+def test_cfg2_iteration_vs_oracle(cga):
+    """BASELINE.json configs[1]: glasses 128x128, council 1 -- one generator / discriminator pair, no council step."""
+    cfg = _cfg("glasses_council_folder.yaml", 1)
+    errs = P.iteration_vs_oracle(cga, cfg, 128, 2, seed=2, report="cfg2 glasses 128^2 council 1 B2")
+    assert "loss/disc_total" not in errs
+
+
+def test_anime_b2a_iteration_vs_oracle(cga):
+    """configs[4]'s model family at full width: anime2face (b2a only, three mask channels), 128x128, council 2."""
+    cfg = _cfg("anime2face_council_folder.yaml", 2)
+    P.iteration_vs_oracle(cga, cfg, 128, 1, seed=3, report="anime2face 128^2 council 2 B1")
+
+
+def test_large_weights_survive_the_split(cga):
+    """Split-precision weights carry a power-of-two scale chosen from the flat buffer's magnitude (not a fixed 2^10):
+    a loaded checkpoint with |w| up to 1e3 must neither saturate nor lose its low bits."""
+    from council_gan_amd import ops
+    torch.manual_seed(0)
+    for wmax in (1e-3, 1.0, 80.0, 1e3, 3e4):
+        x = torch.randn(2, 64, 16, 16, device='cuda').contiguous(memory_format=torch.channels_last)
+        conv = torch.nn.Conv2d(64, 64, 3, 1, 1).cuda()
+        with torch.no_grad():
+            conv.weight.mul_(wmax / conv.weight.abs().max())
+        opt = cga.FlatAdam(list(conv.parameters()), lr=1e-4)
+        opt.materialize('cuda')
+        mgr = ops.SplitWeights(opt)
+        ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        with torch.no_grad():
+            y = ops.conv2d(x, conv.weight, conv.bias, 1, 1, 'none', wmgr=mgr)
+        e = float((y.double() - ref).abs().max() / ref.abs().max())
+        assert e < 2e-6, (wmax, e)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# SURVEY.md 8f pinned to the reference
+# ----------------------------------------------------------------------------------------------------------------------
+def _patch_randn(queue):
+    def randn(*shape, **k):
+        return torch.from_numpy(np.array(queue.pop(0)))
+    torch.randn = randn
+
+
+def _patch_choice(queue):
+    def choice(seq):
+        c = int(queue.pop(0))
+        assert c in seq
+        return c
+    random.choice = choice
+
+
+def _build(cga, g):
+    tr = cga.Council_Trainer(copy.deepcopy(g.cfg), 'cuda:0')
+    state = g.init_state()
+    for d in state:
+        for net, attr in (('gen', 'gen_%s_s'), ('dis', 'dis_%s_s'), ('dis_council', 'dis_council_%s_s')):
+            if net not in state[d]:
+                continue
+            for i, sd in enumerate(state[d][net]):
+                getattr(tr, attr % d)[i].load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+    tr.cuda('cuda:0')
+    return tr
+
+
+@pytest.mark.parametrize("tag", ["mask", "recon"])
+@pytest.mark.parametrize("name", case_names())
+def test_sample_vs_reference(cga, name, tag):
+    """8f.1: `sample()` against the 8-tuple the reference returned (trainer_council.py:643-733, layout :720-733) from
+    the same weights, display styles and fresh style noise."""
+    g = Golden(name)
+    tr = _build(cga, g)
+    n = int(g["sample/n"])
+    x_a, x_b = torch.from_numpy(g["x_a"])[:n].cuda(), torch.from_numpy(g["x_b"])[:n].cuda()
+    tr.s_a, tr.s_b = torch.from_numpy(g["sample/s_a"]).cuda(), torch.from_numpy(g["sample/s_b"]).cuda()
+    noise = list(g["sample/%s/randn" % tag])
+    _patch_randn(noise)
+    out = tr.sample(x_a, x_b, return_mask=(tag == "mask"))
+    assert not noise, "sample() drew fewer style tensors than the reference"
+    assert len(out) == 8 and [int(o is None) for o in out] == list(g["sample/%s/none" % tag])
+    errs = {}
+    for k, o in enumerate(out):
+        if o is not None:
+            ref = g["sample/%s/%d" % (tag, k)]
+            assert tuple(o.shape) == ref.shape, (k, tuple(o.shape), ref.shape)
+            errs[k] = rel_err(P.np_(o), ref)
+    assert max(errs.values()) < P.ACT_TOL, errs
+
+
+@pytest.mark.parametrize("name", case_names("ckpt"))
+def test_resume_from_reference_checkpoint(cga, name, tmp_path):
+    """8f.2: resume() from the checkpoint set the reference's save() wrote (trainer_council.py:969-992), then one
+    iteration -- against the iteration a fresh reference trainer computed after its own resume() (:898-967)."""
+    g = Golden(name)
+    cfg = copy.deepcopy(g.cfg)
+    for k in g.z.files:
+        if k.startswith("ckpt/"):
+            (tmp_path / k[5:]).write_bytes(g[k].tobytes())
+    O.seed_all(123)                          # arbitrary initial weights: everything must come from the files
+    tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+    tr.cuda('cuda:0')
+    assert tr.resume(str(tmp_path), cfg) == int(g["resume/iterations"])
+    x_a, x_b = torch.from_numpy(g["x_a"]), torch.from_numpy(g["x_b"])
+    cfg["iteration"] += 1
+    pre = "resume/"
+    kinds = {"dis": "dis_%s_s", "disc": "dis_council_%s_s", "gen": "gen_%s_s"}
+
+    def check(kind):
+        for d in g.dirs:
+            for i in range(g.C):
+                m = getattr(tr, kinds[kind] % d)[i]
+                gs, ws = P.grads_of(m), P.weights_of(m)
+                ref = g[pre + "%s/gradsum/%s/%d" % (kind, d, i)]
+                mine = summary(gs)
+                assert mine.shape == ref.shape
+                scale = ref[:, 1].max()
+                tol = ACT = P.ACT_TOL if kind != "gen" else 1e-2      # tiny-width generator: norms only, noise 2-4e-3
+                assert np.all(np.abs(mine[:, 1] - ref[:, 1]) <= tol * ref[:, 1] + 1e-5 * scale), (kind, d, i)
+                refw, minew = g[pre + "%s/postsum/%s/%d" % (kind, d, i)], summary(ws)
+                assert np.all(np.abs(minew[:, 1] - refw[:, 1]) <= 1e-4 * refw[:, 1] + 3e-4), (kind, d, i)
+
+    f = P.lossvec
+    _patch_randn(list(g[pre + "dis/randn"]))
+    tr.dis_update(x_a, x_b, cfg)
+    np.testing.assert_allclose(f(tr.loss_dis_total_s), g[pre + "dis/loss_total"], rtol=P.ACT_TOL)
+    check("dis")
+    _patch_randn(list(g[pre + "disc/randn"])); _patch_choice(list(g[pre + "disc/choice"]))
+    tr.dis_council_update(x_a, x_b, cfg)
+    np.testing.assert_allclose(f(tr.loss_dis_council_total_s), g[pre + "disc/loss_total"], rtol=P.ACT_TOL)
+    check("disc")
+    _patch_randn(list(g[pre + "gen/randn"]))
+    tr.gen_update(x_a, x_b, cfg, cfg["iteration"])
+    np.testing.assert_allclose(f(tr.loss_gen_total_s), g[pre + "gen/loss_total"], rtol=P.ACT_TOL)
+    check("gen")
+
+
+def test_our_checkpoints_load_into_torch_adam(cga, tmp_path):
+    """8f.2, the other direction on the GPU box (the reference itself is not there): the optimizer files our save()
+    writes are plain torch.optim.Adam state dicts -- a torch Adam over same-shaped parameters loads them and holds our
+    moments and step counts; the network files hold independent contiguous OIHW tensors."""
+    cfg = _cfg("male2female_council_folder.yaml", 2)
+    cfg['gen'].update(dim=16, mlp_dim=32, n_res=2)
+    cfg['dis'].update(dim=16)
+    cfg['batch_size'] = 2
+    O.seed_all(4)
+    tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+    tr.cuda('cuda:0')
+    x_a, x_b = O.synthetic_batch(2, 64)
+    tr.dis_update(x_a, x_b, cfg); tr.dis_council_update(x_a, x_b, cfg); tr.gen_update(x_a, x_b, cfg, 60000)
+    tr.save(str(tmp_path), 7)
+    ck = torch.load(os.path.join(tmp_path, 'a2b_gen_0_00000008.pt'), map_location='cpu')['a2b']
+    w = ck['enc_content.model.0.conv.weight']
+    assert w.is_contiguous() and w.untyped_storage().nbytes() == w.numel() * 4
+    opt_sd = torch.load(os.path.join(tmp_path, 'optimizer_0.pt'), map_location='cpu')
+    for key, net in (('gen', tr.gen_a2b_s[0]), ('dis', tr.dis_a2b_s[0]), ('dis_council', tr.dis_council_a2b_s[0])):
+        params = [torch.nn.Parameter(torch.zeros(tuple(p.shape))) for p in net.parameters()]
+        adam = torch.optim.Adam(params, lr=1e-4)
+        adam.load_state_dict(opt_sd[key])
+        ours = {'gen': tr.gen_opt_s, 'dis': tr.dis_opt_s, 'dis_council': tr.dis_council_opt_s}[key][0]
+        f = ours.flat
+        n = 0
+        for i, p in enumerate(params):
+            st = adam.state.get(p)
+            if not st:
+                assert ours._steps[i] == 0
+                continue
+            assert int(float(st['step'])) == ours._steps[i] == 1
+            off = f['offs'][i]
+            m = cga.optim._phys_view(f['m'], off, tuple(p.shape)).cpu()
+            assert torch.equal(st['exp_avg'], m) and st['exp_avg'].is_contiguous()
+            n += 1
+        assert n > 0
+        assert adam.param_groups[0]['betas'] == tuple(ours.param_groups[0]['betas'])
