@@ -67,19 +67,26 @@ static_assert(sizeof(GeomS) == offsetof(cg_conv_geom, dy), "GeomS mirrors the he
 struct PipeClass {
     cg_conv_geom g;
     const float* w;
-    int32_t M, K, tiles_n, ntiles;
+    int32_t M, K, tiles_n, ntiles;     // M = output rows of ONE member, ntiles = tiles of one member (grid.x)
     uint32_t w_bytes;
     int32_t pad_;
-    // grouped launches (one class per council member, conv_fwd_x3_kernel only): when xs is set the class brings its own
-    // activation / bias / output / scale pointers instead of the launch-wide ones
-    const void* xs;
-    const float* bias;
-    float* y;
-    const float* x_scale;
 };
 struct PipeBatch {
     PipeClass c[4];
 };
+
+// Member-batched ("grouped") launches: the council members' SAME layer runs as one grid.  Activations of the members
+// are sample blocks of one batched NHWC tensor (member z owns samples [z*N/n, (z+1)*N/n), i.e. output rows
+// [z*M, (z+1)*M)); their parameters sit at a uniform stride in one pool (optim.py), so member z reads its weights /
+// bias `z * stride` further on.  blockIdx.z = member for forward / data-gradient launches, blockIdx.y for
+// weight-gradient launches.  n = 1 is an ordinary launch.
+struct Members {
+    int32_t n;
+    int32_t pad;
+    long long w_stride;     // bytes between consecutive members' weights AS THE KERNEL READS THEM
+    long long b_stride;     // bytes between consecutive members' biases (fp32)
+};
+inline Members one_member() { return Members{1, 0, 0, 0}; }
 
 template <class G>
 __device__ __forceinline__ RowInfo decode_row(const G& g, int m, int M, bool fwd_out) {
@@ -124,8 +131,9 @@ __device__ __forceinline__ void block_amax_store(float vmax, float* __restrict__
         float m = amax_red[0];
 #pragma unroll
         for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, amax_red[w]);
-        if (gridDim.x <= 1024) state[2 + blockIdx.x] = m;
-        else atomicMax(reinterpret_cast<unsigned*>(state + 2 + (blockIdx.x & 1023)), __float_as_uint(m));
+        const unsigned nb = gridDim.x * gridDim.z, b = blockIdx.z * gridDim.x + blockIdx.x;   // members ride on grid.z
+        if (nb <= 1024) state[2 + b] = m;
+        else atomicMax(reinterpret_cast<unsigned*>(state + 2 + (b & 1023)), __float_as_uint(m));
     }
 }
 
@@ -138,7 +146,8 @@ __device__ __forceinline__ void block_amax_store(float vmax, float* __restrict__
 template <int BM, int BN, int WM, int WN, bool FAST, int STAGES>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_kernel(
     cg_conv_geom g, const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ w,
-    const float* __restrict__ bias, float* __restrict__ y, int M, int K, int tiles_n, float* __restrict__ amax_state) {
+    const float* __restrict__ bias, float* __restrict__ y, int M, int K, int tiles_n, float* __restrict__ amax_state,
+    Members mb) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -151,12 +160,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * BM;
+    const int m_lo = (int)blockIdx.z * M;            // this member's rows: [m_lo, m_lo + M)
+    const int m0 = m_lo + (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
     const int Ct = g.C1 + g.C2;
+    w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w) + (long long)blockIdx.z * mb.w_stride);
+    if (bias) bias = reinterpret_cast<const float*>(reinterpret_cast<const char*>(bias) + (long long)blockIdx.z * mb.b_stride);
 
     if (tid < g.T) taps[tid] = load_tap(tid);
-    for (int r = tid; r < BM; r += NT) rows[r] = decode_row(g, m0 + r, M, true);
+    for (int r = tid; r < BM; r += NT) rows[r] = decode_row(g, m0 + r, m_lo + M, true);
     __syncthreads();
 
     f32x16 acc[TM][TN];
@@ -357,7 +369,7 @@ __device__ __forceinline__ void dbg_stamp(int tile, int slot) {
 template <int BM, int BN, int WM, int WN, int PF, int ABL>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kernel(
     PipeBatch batch, const float* __restrict__ x1, const float* __restrict__ bias, float* __restrict__ y,
-    unsigned x_bytes, double* __restrict__ stats) {
+    unsigned x_bytes, double* __restrict__ stats, Members mb) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN);
@@ -384,14 +396,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kern
 #pragma unroll
         for (int i = 0; i < (int)(sizeof(GeomS) / 4); ++i) go[i] = gi[i];
     }
-    const float* __restrict__ w = pc->w;
-    const int M = pc->M, K = pc->K, tiles_n = pc->tiles_n;
+    const float* __restrict__ w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pc->w) + (long long)blockIdx.z * mb.w_stride);
+    if (bias) bias = reinterpret_cast<const float*>(reinterpret_cast<const char*>(bias) + (long long)blockIdx.z * mb.b_stride);
+    const int m_lo = (int)blockIdx.z * pc->M;        // this member's rows: [m_lo, m_lo + pc->M)
+    const int M = m_lo + pc->M, K = pc->K, tiles_n = pc->tiles_n;
     const unsigned w_bytes = pc->w_bytes;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int m0 = (tile / tiles_n) * BM;
+    const int m0 = m_lo + (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
     const int Ct = g.C1;
 
@@ -620,7 +634,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kern
                 a += red[(wmi * BN + tid) * 2];
                 b += red[(wmi * BN + tid) * 2 + 1];
             }
-            double* o = stats + ((size_t)(tile / tiles_n) * g.Cout + n0 + tid) * 2;
+            double* o = stats + ((size_t)(m0 / BM) * g.Cout + n0 + tid) * 2;      // global row tile (members included)
             o[0] = a;
             o[1] = b;
         }
@@ -641,6 +655,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_wgrad_kernel(
                                                          const float* __restrict__ dz, float* __restrict__ out,
                                                          int M, int K, int tiles_n, int slices_per_split,
                                                          int want_bias) {
+    // grouped launches: blockIdx.y = council member; M = output rows of ONE member, whose rows are [m_lo, m_lo + M)
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int BP = 32;  // output positions per stage
@@ -778,9 +793,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_wgrad_kernel(
         }
     };
 
+    const int m_lo = (int)blockIdx.y * M;
     auto decode_rows = [&](int slice, int buf) {
         if (tid < BP) {
-            rows[buf][tid] = decode_row(g, slice * BP + tid, M, false);
+            rows[buf][tid] = decode_row(g, m_lo + slice * BP + tid, m_lo + M, false);
         }
     };
 
@@ -827,8 +843,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_wgrad_kernel(
         }
     }
 
-    // partial layout per split: [Cout*K weight partials | Cout bias partials]
-    float* dst = out + (size_t)split * ((size_t)g.Cout * K + g.Cout);
+    // partial layout per (member, split): [Cout*K weight partials | Cout bias partials]
+    float* dst = out + ((size_t)blockIdx.y * gridDim.z + split) * ((size_t)g.Cout * K + g.Cout);
     if (do_bias && co0 + tid < g.Cout) dst[(size_t)g.Cout * K + co0 + tid] = bsum;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -918,19 +934,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_wgrad_pipe_ke
 
     float4 dv[D_V4], xv[X_V4];
     int ld_s = s_begin;  // slice the next load_tile() fetches (clamped to the last slice of this split)
+    const int m_lo = (int)blockIdx.y * M, m_hi = m_lo + M;     // grouped launches: blockIdx.y = member, M = ITS rows
     auto load_tile = [&]() {
-        const int mb = ld_s * BP;
+        const int mb = m_lo + ld_s * BP;
 #pragma unroll
         for (int i = 0; i < D_V4; ++i) {
             const int m = mb + d_r0 + D_RP * i;
-            dv[i] = buf_load4(dr, ((((unsigned)m * (unsigned)g.Cout) + d_col) << 2) | d_oob | (m < M ? 0u : CG_OOB));
+            dv[i] = buf_load4(dr, ((((unsigned)m * (unsigned)g.Cout) + d_col) << 2) | d_oob | (m < m_hi ? 0u : CG_OOB));
         }
 #pragma unroll
         for (int i = 0; i < X_V4; ++i) {
             const int m = mb + x_r0 + X_RP * i;
             const int n = m >> lg_hw, rem = m & hw_mask;
             const int ly = (rem >> lg_wo) * g.stride + dy, lx = (rem & wo_mask) * g.stride + dx;
-            const bool ok = m < M && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
+            const bool ok = m < m_hi && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
             const unsigned pix = (unsigned)(n * img + (ly >> g.up) * g.W + (lx >> g.up));
             xv[i] = buf_load4(xr, ((pix * (unsigned)Ct + x_col) << 2) | (ok ? 0u : CG_OOB));
         }
@@ -1022,8 +1039,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_wgrad_pipe_ke
         if (nk & 1) slice(I0());
     }
 
-    // partial layout per split: [Cout*K weight partials | Cout bias partials]
-    float* dst = out + (size_t)split * ((size_t)g.Cout * K + g.Cout);
+    // partial layout per (member, split): [Cout*K weight partials | Cout bias partials]
+    float* dst = out + ((size_t)blockIdx.y * gridDim.z + split) * ((size_t)g.Cout * K + g.Cout);
     if (do_bias && co0 + tid < g.Cout) dst[(size_t)g.Cout * K + co0 + tid] = bsum;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -1045,12 +1062,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_wgrad_pipe_ke
 template <int L>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                             float* __restrict__ dbias, size_t nw, int nb, int splits,
-                                                            int accumulate) {
+                                                            int accumulate, long long w_mstride, long long b_mstride) {
+    // blockIdx.y = council member: its partial blocks follow the previous member's, its gradients live *_mstride floats on
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t i = t / L;
     const int j = (int)(t % L);
     const size_t stride = nw + (size_t)nb;
     const size_t n = nw + (dbias ? (size_t)nb : 0);
+    part += (size_t)blockIdx.y * splits * stride;
+    dw += (long long)blockIdx.y * w_mstride;
+    if (dbias) dbias += (long long)blockIdx.y * b_mstride;
     float s = 0.f;
     if (i < n)
         for (int k = j; k < splits; k += L) s += part[(size_t)k * stride + i];
@@ -1082,12 +1103,19 @@ struct TransArgs {  // the kernel's kernarg layout (for the offset of the table)
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ out,
                                                                int Cout, int T, int Cin, int ci0, int nci, TransTable tt,
-                                                               float scale, unsigned lo_elems) {
+                                                               float scale, unsigned lo_elems, int nz, long long w_mstride,
+                                                               long long out_mstride, const float* __restrict__ scale_dev) {
+    // blockIdx.z = member * nz + table entry; member m reads w + m*w_mstride floats and writes out + m*out_mstride
+    // (floats for the fp32 layout, fp16 ELEMENTS -- i.e. 4 bytes each in the interleaved {hi, lo} form -- when SPLIT)
     __shared__ float tile[32][33];
     typedef const __attribute__((address_space(4))) int32_t* KI;
     KI tab = (KI)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
                   offsetof(TransArgs, tt));
-    const int z = blockIdx.z;
+    const int member = blockIdx.z / nz;
+    const int z = blockIdx.z - member * nz;
+    w += (long long)member * w_mstride;
+    out += (long long)member * out_mstride;
+    if (SPLIT && scale_dev) scale = scale_dev[0];
     const int tap = tab[z], base = tab[CG_MAX_TAPS + z], tc = tab[2 * CG_MAX_TAPS + z], Tc = tab[3 * CG_MAX_TAPS + z];
     const int cib = blockIdx.x * 32, cob = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -1194,31 +1222,51 @@ static int amax_slots_for(long blocks, float* state, hipStream_t st) {
     return CG_AMAX_SLOTS_MAX;
 }
 
+// ---- member grouping on the host side -----------------------------------------------------------------------------
+// cg_group (public): n members whose parameters sit `stride` fp32 ELEMENTS apart (weights, biases and their gradients
+// alike: one pool per optimizer kind, optim.py).  A NULL group or n == 1 is an ordinary single-member call.
+struct Grp {
+    int n = 1;
+    long long stride = 0;      // elements
+};
+static int grp_from(const cg_group* g, int N, Grp& out, const char* who) {
+    out = Grp();
+    if (!g) return CG_OK;
+    CG_CHECK_ARG(g->n >= 1 && g->n <= 64, "%s: group of %d members (1..64)", who, g->n);
+    CG_CHECK_ARG(N % g->n == 0, "%s: batch %d is not a multiple of the %d members", who, N, g->n);
+    CG_CHECK_ARG(g->n == 1 || g->stride > 0, "%s: grouped launch needs the members' parameter stride", who);
+    out.n = g->n;
+    out.stride = g->n > 1 ? (long long)g->stride : 0;
+    return CG_OK;
+}
+static Members members_f32(const Grp& gr) { return Members{gr.n, 0, gr.stride * 4, gr.stride * 4}; }
+
 template <int BM, int BN, int WM, int WN, int STAGES>
 int launch_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias, float* y,
-               int M, int K, bool fast, hipStream_t st) {
+               int M, int K, bool fast, hipStream_t st, const Grp& gr) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (g->Cout + BN - 1) / BN;
-    dim3 grid(tiles_m * tiles_n), block(NT);
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (g->Cout + BN - 1) / BN;     // M = rows of one member
+    dim3 grid(tiles_m * tiles_n, 1, gr.n), block(NT);
     float* amax = nullptr;
     if (fwd_amax.state && g->osy == 1 && g->osx == 1) {
-        fwd_amax.nslots = amax_slots_for((long)tiles_m * tiles_n, fwd_amax.state, st);
+        fwd_amax.nslots = amax_slots_for((long)tiles_m * tiles_n * gr.n, fwd_amax.state, st);
         if (fwd_amax.nslots) amax = fwd_amax.state;
     }
-    ProfScope prof(0, BM, BN, fast, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
+    ProfScope prof(0, BM, BN, fast, 2.0 * (double)M * gr.n * (double)g->Cout * (double)K, st, g, gr.n);
+    const Members mb = members_f32(gr);
     if (fast)
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true, STAGES>), grid, block, 0, st, *g, x1, x2, w, bias, y, M,
-                           K, tiles_n, amax);
+                           K, tiles_n, amax, mb);
     else
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false, STAGES>), grid, block, 0, st, *g, x1, x2, w, bias, y,
-                           M, K, tiles_n, amax);
+                           M, K, tiles_n, amax, mb);
     CG_LAUNCH_CHECK("conv_fwd_kernel");
     return CG_OK;
 }
 
 template <int BM, int BN, int WM, int WN, int PF = 1, int ABL = 0>
 int launch_pipe_batch(PipeBatch& b, int ncls, const float* x1, const float* bias, float* y, unsigned x_bytes, hipStream_t st,
-                      double* stats = nullptr, int* stats_rows = nullptr) {
+                      double* stats, const Members& mb) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     int max_tiles = 0;
     double flops = 0.0;
@@ -1227,52 +1275,44 @@ int launch_pipe_batch(PipeBatch& b, int ncls, const float* x1, const float* bias
         pc.tiles_n = (pc.g.Cout + BN - 1) / BN;
         pc.ntiles = ((pc.M + BM - 1) / BM) * pc.tiles_n;
         if (pc.ntiles > max_tiles) max_tiles = pc.ntiles;
-        flops += 2.0 * (double)pc.M * (double)pc.g.Cout * (double)pc.K;
+        flops += 2.0 * (double)pc.M * (double)pc.g.Cout * (double)pc.K * mb.n;
     }
     for (int c = ncls; c < 4; ++c) b.c[c].ntiles = 0;
-    dim3 grid(max_tiles, ncls), block(NT);
-    ProfScope prof(2, BM, BN, true, flops, st, &b.c[0].g, ncls);
-    if (stats_rows) *stats_rows = BM;
-    hipLaunchKernelGGL((conv_fwd_pipe_kernel<BM, BN, WM, WN, PF, ABL>), grid, block, 0, st, b, x1, bias, y, x_bytes, stats);
+    dim3 grid(max_tiles, ncls, mb.n), block(NT);
+    ProfScope prof(2, BM, BN, true, flops, st, &b.c[0].g, ncls * mb.n);
+    hipLaunchKernelGGL((conv_fwd_pipe_kernel<BM, BN, WM, WN, PF, ABL>), grid, block, 0, st, b, x1, bias, y, x_bytes, stats, mb);
     CG_LAUNCH_CHECK("conv_fwd_pipe_kernel");
     return CG_OK;
 }
 
-// configurations whose launch forwards the statistics pointer to the kernel (the measurement variants 27-31 do not)
+// configurations whose launch forwards the statistics pointer to the kernel
 bool pipe_cfg_has_stats(int cfg) { return (cfg >= 20 && cfg <= 26) || cfg == 32; }
 int pipe_cfg_bm(int cfg) { return cfg == 23 || cfg == 26 ? 64 : (cfg == 24 || cfg == 32 ? 256 : 128); }
 
 int launch_pipe_cfg(int cfg, PipeBatch& b, int ncls, const float* x1, const float* bias, float* y, unsigned x_bytes,
-                    hipStream_t st, double* stats = nullptr) {
+                    hipStream_t st, double* stats, const Members& mb) {
     switch (cfg) {
-        case 20: return launch_pipe_batch<128, 128, 64, 32>(b, ncls, x1, bias, y, x_bytes, st, stats);  // 8 waves
-        case 21: return launch_pipe_batch<128, 128, 64, 64>(b, ncls, x1, bias, y, x_bytes, st, stats);  // 4 waves
-        case 22: return launch_pipe_batch<128, 64, 64, 32>(b, ncls, x1, bias, y, x_bytes, st, stats);   // 4 waves
-        case 23: return launch_pipe_batch<64, 64, 32, 32>(b, ncls, x1, bias, y, x_bytes, st, stats);    // 4 waves
-        case 24: return launch_pipe_batch<256, 128, 64, 64>(b, ncls, x1, bias, y, x_bytes, st, stats);  // 8 waves
-        case 25: return launch_pipe_batch<128, 64, 32, 32>(b, ncls, x1, bias, y, x_bytes, st, stats);   // 8 waves
-        case 26: return launch_pipe_batch<64, 128, 32, 64>(b, ncls, x1, bias, y, x_bytes, st, stats);   // 4 waves
-        case 27: return launch_pipe_batch<128, 128, 64, 32, 2>(b, ncls, x1, bias, y, x_bytes, st);     // prefetch 2
-        case 28: return launch_pipe_batch<128, 128, 64, 32, 1, 1>(b, ncls, x1, bias, y, x_bytes, st);  // ablation
-        case 29: return launch_pipe_batch<128, 128, 64, 32, 1, 2>(b, ncls, x1, bias, y, x_bytes, st);  // ablation
-        case 30: return launch_pipe_batch<128, 128, 64, 64, 2>(b, ncls, x1, bias, y, x_bytes, st);     // 4 waves, prefetch 2
-        case 31: return launch_pipe_batch<128, 128, 64, 32, 1, 3>(b, ncls, x1, bias, y, x_bytes, st);  // timing probe
-        case 32: return launch_pipe_batch<256, 64, 64, 32>(b, ncls, x1, bias, y, x_bytes, st, stats);  // 8 waves
+        case 20: return launch_pipe_batch<128, 128, 64, 32>(b, ncls, x1, bias, y, x_bytes, st, stats, mb);  // 8 waves
+        case 21: return launch_pipe_batch<128, 128, 64, 64>(b, ncls, x1, bias, y, x_bytes, st, stats, mb);  // 4 waves
+        case 22: return launch_pipe_batch<128, 64, 64, 32>(b, ncls, x1, bias, y, x_bytes, st, stats, mb);   // 4 waves
+        case 23: return launch_pipe_batch<64, 64, 32, 32>(b, ncls, x1, bias, y, x_bytes, st, stats, mb);    // 4 waves
+        case 24: return launch_pipe_batch<256, 128, 64, 64>(b, ncls, x1, bias, y, x_bytes, st, stats, mb);  // 8 waves
+        case 25: return launch_pipe_batch<128, 64, 32, 32>(b, ncls, x1, bias, y, x_bytes, st, stats, mb);   // 8 waves
+        case 26: return launch_pipe_batch<64, 128, 32, 64>(b, ncls, x1, bias, y, x_bytes, st, stats, mb);   // 4 waves
+        case 31: return launch_pipe_batch<128, 128, 64, 32, 1, 3>(b, ncls, x1, bias, y, x_bytes, st, nullptr, mb);  // timing probe
+        case 32: return launch_pipe_batch<256, 64, 64, 32>(b, ncls, x1, bias, y, x_bytes, st, stats, mb);  // 8 waves
         default: return cg_set_error(CG_ERR_ARG, "pipelined conv: unknown tile configuration %d", cfg);
     }
 }
 
-void fill_class(PipeClass& pc, const cg_conv_geom* g, const float* w) {
+// one class of a (possibly grouped) launch: M = output rows of ONE member
+void fill_class(PipeClass& pc, const cg_conv_geom* g, const float* w, int nmember = 1) {
     pc.g = *g;
     pc.w = w;
-    pc.M = g->N * g->Ho * g->Wo;
+    pc.M = (g->N / nmember) * g->Ho * g->Wo;
     pc.K = g->T * g->C1;
     pc.w_bytes = (unsigned)((size_t)g->Cout * pc.K * sizeof(float));
     pc.pad_ = 0;
-    pc.xs = nullptr;
-    pc.bias = nullptr;
-    pc.y = nullptr;
-    pc.x_scale = nullptr;
 }
 
 #include "conv_x3.inc"
@@ -1292,46 +1332,47 @@ bool pipe_ok(const cg_conv_geom* g, int K) {
            (size_t)g->Cout * K * sizeof(float) < (size_t)CG_OOB;
 }
 
-// tile configurations of the forward kernel (id -> BM, BN, WM, WN, STAGES)
+// tile configurations of the forward kernel (id -> BM, BN, WM, WN, STAGES); M = rows of one member
 int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
-                   float* y, int M, int K, bool fast, hipStream_t st, double* stats = nullptr) {
+                   float* y, int M, int K, bool fast, hipStream_t st, double* stats, const Grp& gr) {
+#define FW(...) return launch_fwd<__VA_ARGS__>(g, x1, x2, w, bias, y, M, K, fast, st, gr)
     switch (cfg) {
-        case 0: return launch_fwd<128, 128, 64, 64, 1>(g, x1, x2, w, bias, y, M, K, fast, st);
-        case 1: return launch_fwd<128, 64, 64, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);
-        case 2: return launch_fwd<128, 32, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);
-        case 3: return launch_fwd<64, 64, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);
-        case 4: return launch_fwd<128, 128, 64, 64, 2>(g, x1, x2, w, bias, y, M, K, fast, st);
-        case 5: return launch_fwd<128, 64, 64, 32, 2>(g, x1, x2, w, bias, y, M, K, fast, st);
-        case 6: return launch_fwd<128, 128, 64, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
-        case 7: return launch_fwd<128, 128, 64, 32, 2>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
-        case 8: return launch_fwd<64, 128, 32, 64, 1>(g, x1, x2, w, bias, y, M, K, fast, st);
-        case 9: return launch_fwd<64, 128, 32, 64, 2>(g, x1, x2, w, bias, y, M, K, fast, st);
-        case 10: return launch_fwd<64, 64, 32, 32, 2>(g, x1, x2, w, bias, y, M, K, fast, st);
-        case 11: return launch_fwd<256, 128, 64, 64, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 8 waves
-        case 12: return launch_fwd<256, 128, 64, 64, 2>(g, x1, x2, w, bias, y, M, K, fast, st);  // 8 waves
-        case 13: return launch_fwd<128, 32, 32, 32, 2>(g, x1, x2, w, bias, y, M, K, fast, st);
-        case 14: return launch_fwd<128, 64, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
-        case 15: return launch_fwd<256, 64, 64, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
-        case 16: return launch_fwd<64, 128, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);   // 8 waves
-        case 17: return launch_fwd<128, 128, 32, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 16 waves
-        case 18: return launch_fwd<256, 128, 64, 32, 1>(g, x1, x2, w, bias, y, M, K, fast, st);  // 16 waves
-        case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31:
-        case 32: {
+        case 0: FW(128, 128, 64, 64, 1);
+        case 1: FW(128, 64, 64, 32, 1);
+        case 2: FW(128, 32, 32, 32, 1);
+        case 3: FW(64, 64, 32, 32, 1);
+        case 4: FW(128, 128, 64, 64, 2);
+        case 5: FW(128, 64, 64, 32, 2);
+        case 6: FW(128, 128, 64, 32, 1);   // 8 waves
+        case 7: FW(128, 128, 64, 32, 2);   // 8 waves
+        case 8: FW(64, 128, 32, 64, 1);
+        case 9: FW(64, 128, 32, 64, 2);
+        case 10: FW(64, 64, 32, 32, 2);
+        case 11: FW(256, 128, 64, 64, 1);  // 8 waves
+        case 12: FW(256, 128, 64, 64, 2);  // 8 waves
+        case 13: FW(128, 32, 32, 32, 2);
+        case 14: FW(128, 64, 32, 32, 1);   // 8 waves
+        case 15: FW(256, 64, 64, 32, 1);   // 8 waves
+        case 16: FW(64, 128, 32, 32, 1);   // 8 waves
+        case 17: FW(128, 128, 32, 32, 1);  // 16 waves
+        case 18: FW(256, 128, 64, 32, 1);  // 16 waves
+        case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 31: case 32: {
             if (!pipe_ok(g, K)) return cg_set_error(CG_ERR_ARG, "conv forward: configuration %d needs the pipelined path", cfg);
             PipeBatch b;
-            fill_class(b.c[0], g, w);
+            fill_class(b.c[0], g, w, gr.n);
             return launch_pipe_cfg(cfg, b, 1, x1, bias, y, (unsigned)((size_t)g->N * g->H * g->W * g->C1 * sizeof(float)), st,
-                                   stats);
+                                   stats, members_f32(gr));
         }
         default: return cg_set_error(CG_ERR_ARG, "conv forward: unknown tile configuration %d", cfg);
     }
+#undef FW
 }
 
 // Measured on MI355X (profiles/r01_conv_tiles.txt): 8-wave 128x128 blocks (two waves per SIMD hide each
 // other's barrier / LDS phases) reach 112-123 TFLOP/s once >= ~192 such tiles exist; problems with
-// fewer tiles fill the 256 CUs better with 64x64 tiles (two LDS stages when very few tiles).
-int pick_fwd_cfg(const cg_conv_geom* g, int M, bool pipe) {
-    const long blocks128 = (long)((M + 127) / 128) * ((g->Cout + 127) / 128);
+// fewer tiles fill the 256 CUs better with 64x64 tiles (two LDS stages when very few tiles).  M = rows of the LAUNCH.
+int pick_fwd_cfg(const cg_conv_geom* g, long M, bool pipe) {
+    const long blocks128 = ((M + 127) / 128) * ((g->Cout + 127) / 128);
     if (g->Cout > 64) {
         if (blocks128 >= 192) return pipe ? 20 : 6;
         if (pipe) return 23;
@@ -1355,14 +1396,17 @@ struct WgradPlan {
     int tiles_m, tiles_n, splits, slices_per_split;
 };
 
-WgradPlan plan_wgrad(const cg_conv_geom* g) {
+// Split plan of ONE member's weight gradient (M = its output rows).  A grouped launch runs the members' identical plans
+// side by side (grid.y), so a member's result does not depend on how many members share the launch; with several members
+// fewer splits per member already fill the chip.
+WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1) {
     // Every instantiated tile has exactly four 32x32 MFMA wave tiles or more (4 waves / block):
     //   bm=128: bn in {128, 64, 32};  bm=64: bn in {128, 64};  bm=32: bn = 128.
     // FAST (float4 gather, one tap per k-tile) needs a single source and Ct % bn == 0.
     WgradPlan p;
     const int Ct = g->C1 + g->C2;
     const int K = g->T * Ct;
-    const int M = g->N * g->Ho * g->Wo;
+    const int M = (g->N / nmember) * g->Ho * g->Wo;
     p.bm = g->Cout > 64 ? 128 : (g->Cout > 32 ? 64 : 32);
     const int bn_min = p.bm == 128 ? 32 : (p.bm == 64 ? 64 : 128);
     p.fast = false;
@@ -1379,8 +1423,9 @@ WgradPlan plan_wgrad(const cg_conv_geom* g) {
     p.tiles_m = (g->Cout + p.bm - 1) / p.bm;
     p.tiles_n = (K + p.bn - 1) / p.bn;
     const int slices = (M + 31) / 32;
-    const int tiles = p.tiles_m * p.tiles_n;
+    const int tiles = p.tiles_m * p.tiles_n * nmember;
     int want = (2 * 256) / tiles;                      // two co-resident blocks per CU, and no partial second round
+    if (want < 1) want = 1;
     if (K <= 128 && g->Cout <= 128) want *= 4;         // 1x1-class gradients are bandwidth-bound: more loads in flight
     int max_by_work = slices / 8 > 0 ? slices / 8 : 1; // >= 8 slices (256 positions) per split
     int s = want < max_by_work ? want : max_by_work;
@@ -1393,9 +1438,9 @@ WgradPlan plan_wgrad(const cg_conv_geom* g) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_wgrad(const cg_conv_geom* g, const WgradPlan& p, const float* x1, const float* x2, const float* dz,
-                 float* out, int M, int K, int want_bias, hipStream_t st) {
-    dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits), block((BM / WM) * (BN / WN) * 64);
-    ProfScope prof(1, BM, BN, p.fast, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
+                 float* out, int M, int K, int want_bias, hipStream_t st, int nmember) {
+    dim3 grid(p.tiles_m * p.tiles_n, nmember, p.splits), block((BM / WM) * (BN / WN) * 64);
+    ProfScope prof(1, BM, BN, p.fast, 2.0 * (double)M * nmember * (double)g->Cout * (double)K, st, g, nmember);
     if (p.fast)
         hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, *g, x1, x2, dz, out, M, K,
                            p.tiles_n, p.slices_per_split, want_bias);
@@ -1413,48 +1458,82 @@ int ilog2_exact(int v) {  // log2 of a power of two, -1 otherwise
     return l;
 }
 
-bool wgrad_pipe_ok(const cg_conv_geom* g, const WgradPlan& p, int M) {
+bool wgrad_pipe_ok(const cg_conv_geom* g, const WgradPlan& p) {
     if (!p.fast || g->C2 != 0 || (g->Cout & 3)) return false;
     if (ilog2_exact(g->Ho * g->Wo) < 0 || ilog2_exact(g->Wo) < 0) return false;
     if (!((p.bm == 128 && p.bn == 128) || (p.bm == 128 && p.bn == 64) || (p.bm == 64 && p.bn == 64) ||
           (p.bm == 64 && p.bn == 128)))
         return false;
     return (size_t)g->N * g->H * g->W * g->C1 * sizeof(float) < (size_t)CG_OOB &&
-           (size_t)M * g->Cout * sizeof(float) < (size_t)CG_OOB;
+           (size_t)g->N * g->Ho * g->Wo * g->Cout * sizeof(float) < (size_t)CG_OOB;
 }
 
 template <int BM, int BN, int WM, int WN>
 int launch_wgrad_pipe(const cg_conv_geom* g, const WgradPlan& p, const float* x1, const float* dz, float* out, int M, int K,
-                      int want_bias, hipStream_t st) {
-    dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits), block((BM / WM) * (BN / WN) * 64);
-    ProfScope prof(3, BM, BN, true, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
+                      int want_bias, hipStream_t st, int nmember) {
+    dim3 grid(p.tiles_m * p.tiles_n, nmember, p.splits), block((BM / WM) * (BN / WN) * 64);
+    ProfScope prof(3, BM, BN, true, 2.0 * (double)M * nmember * (double)g->Cout * (double)K, st, g, nmember);
     hipLaunchKernelGGL((conv_wgrad_pipe_kernel<BM, BN, WM, WN>), grid, block, 0, st, *g, x1, dz, out, M, K, p.tiles_n,
                        p.slices_per_split, want_bias, ilog2_exact(g->Ho * g->Wo), ilog2_exact(g->Wo),
                        (unsigned)((size_t)g->N * g->H * g->W * g->C1 * sizeof(float)),
-                       (unsigned)((size_t)M * g->Cout * sizeof(float)));
+                       (unsigned)((size_t)g->N * g->Ho * g->Wo * g->Cout * sizeof(float)));
     CG_LAUNCH_CHECK("conv_wgrad_pipe_kernel");
+    return CG_OK;
+}
+
+// partials of (member, split) -> the members' gradient tensors, fixed order
+int launch_splitk_reduce(const float* part, float* dw, float* dbias, size_t nw, int Cout, int splits, int accumulate,
+                         const Grp& gr, hipStream_t st) {
+    const size_t n = nw + (dbias ? Cout : 0);
+    const long long ms = gr.stride;
+    if (splits >= 128)
+        hipLaunchKernelGGL(splitk_reduce_kernel<64>, dim3(cg_div_up(n * 64, 256), gr.n), dim3(256), 0, st, part, dw, dbias, nw,
+                           Cout, splits, accumulate, ms, ms);
+    else if (splits >= 24)
+        hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(cg_div_up(n * 8, 256), gr.n), dim3(256), 0, st, part, dw, dbias, nw,
+                           Cout, splits, accumulate, ms, ms);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cg_div_up(n, 256), gr.n), dim3(256), 0, st, part, dw, dbias, nw, Cout,
+                           splits, accumulate, ms, ms);
+    CG_LAUNCH_CHECK("splitk_reduce_kernel");
     return CG_OK;
 }
 
 }  // namespace
 
-static int conv2d_fwd_impl(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
-                           float* y, int cfg, cg_stream_t stream) {
-    int rc = validate_geom(g, "cg_conv2d_fwd");
+// ---- forward ------------------------------------------------------------------------------------------------------
+// One implementation behind every fp32 forward entry point: optional instance-norm partials (`stats`), optional
+// per-block output maxima (through the thread-local fwd_amax), optional member grouping.
+static int conv2d_fwd_impl(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2, const float* w,
+                           const float* bias, float* y, int cfg, double* stats, size_t stats_bytes, int* rows_per_partial,
+                           cg_stream_t stream, const char* who) {
+    if (rows_per_partial) *rows_per_partial = 0;
+    int rc = validate_geom(g, who);
     if (rc) return rc;
-    CG_CHECK_ARG(x1 && w && y, "cg_conv2d_fwd: null pointer");
-    CG_CHECK_ARG(g->C2 == 0 || x2, "cg_conv2d_fwd: C2 > 0 needs x2");
+    CG_CHECK_ARG(x1 && w && y, "%s: null pointer", who);
+    CG_CHECK_ARG(g->C2 == 0 || x2, "%s: C2 > 0 needs x2", who);
+    Grp gr;
+    rc = grp_from(group, g->N, gr, who);
+    if (rc) return rc;
     const int Ct = g->C1 + g->C2;
     const int K = g->T * Ct;
-    const int M = g->N * g->Ho * g->Wo;
+    const int Mm = (g->N / gr.n) * g->Ho * g->Wo;          // rows of one member
     const bool fast = (g->C2 == 0) && (Ct % 32 == 0);
-    if (cfg < 0) cfg = pick_fwd_cfg(g, M, fast && pipe_ok(g, K));
-    return launch_fwd_cfg(cfg, g, x1, x2, w, bias, y, M, K, fast, cg_s(stream));
+    if (cfg < 0) cfg = pick_fwd_cfg(g, (long)Mm * gr.n, fast && pipe_ok(g, K));
+    double* st_ptr = nullptr;
+    if (rows_per_partial && pipe_cfg_has_stats(cfg) && stats && g->act == CG_ACT_NONE && g->osy == 1 && g->osx == 1) {
+        const int bm = pipe_cfg_bm(cfg);
+        if ((g->Ho * g->Wo) % bm == 0 && stats_bytes >= (size_t)((size_t)Mm * gr.n / bm) * g->Cout * 2 * sizeof(double)) {
+            st_ptr = stats;
+            *rows_per_partial = bm;
+        }
+    }
+    return launch_fwd_cfg(cfg, g, x1, x2, w, bias, y, Mm, K, fast, cg_s(stream), st_ptr, gr);
 }
 
 extern "C" int cg_conv2d_fwd(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
                              const float* bias, float* y, cg_stream_t stream) {
-    return conv2d_fwd_impl(g, x1, x2, w, bias, y, -1, stream);
+    return conv2d_fwd_impl(g, nullptr, x1, x2, w, bias, y, -1, nullptr, 0, nullptr, stream, "cg_conv2d_fwd");
 }
 
 extern "C" int cg_conv2d_fwd_amax(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
@@ -1462,7 +1541,7 @@ extern "C" int cg_conv2d_fwd_amax(const cg_conv_geom* g, const float* x1, const 
     CG_CHECK_ARG(amax_state && amax_nslots, "cg_conv2d_fwd_amax: null pointer");
     fwd_amax.state = amax_state;
     fwd_amax.nslots = 0;
-    const int rc = conv2d_fwd_impl(g, x1, x2, w, bias, y, -1, stream);
+    const int rc = conv2d_fwd_impl(g, nullptr, x1, x2, w, bias, y, -1, nullptr, 0, nullptr, stream, "cg_conv2d_fwd_amax");
     *amax_nslots = rc ? 0 : fwd_amax.nslots;
     fwd_amax.state = nullptr;
     return rc;
@@ -1471,25 +1550,28 @@ extern "C" int cg_conv2d_fwd_amax(const cg_conv_geom* g, const float* x1, const 
 extern "C" int cg_conv2d_fwd_stats(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
                                    const float* bias, float* y, double* stats, size_t stats_bytes, int* rows_per_partial,
                                    cg_stream_t stream) {
-    int rc = validate_geom(g, "cg_conv2d_fwd_stats");
-    if (rc) return rc;
-    CG_CHECK_ARG(x1 && w && y && rows_per_partial, "cg_conv2d_fwd_stats: null pointer");
-    CG_CHECK_ARG(g->C2 == 0 || x2, "cg_conv2d_fwd_stats: C2 > 0 needs x2");
-    const int Ct = g->C1 + g->C2;
-    const int K = g->T * Ct;
-    const int M = g->N * g->Ho * g->Wo;
-    const bool fast = (g->C2 == 0) && (Ct % 32 == 0);
-    const int cfg = pick_fwd_cfg(g, M, fast && pipe_ok(g, K));
-    *rows_per_partial = 0;
-    double* st_ptr = nullptr;
-    if (pipe_cfg_has_stats(cfg) && stats && g->act == CG_ACT_NONE && g->osy == 1 && g->osx == 1) {
-        const int bm = pipe_cfg_bm(cfg);
-        if ((g->Ho * g->Wo) % bm == 0 && stats_bytes >= (size_t)(M / bm) * g->Cout * 2 * sizeof(double)) {
-            st_ptr = stats;
-            *rows_per_partial = bm;
-        }
-    }
-    return launch_fwd_cfg(cfg, g, x1, x2, w, bias, y, M, K, fast, cg_s(stream), st_ptr);
+    CG_CHECK_ARG(rows_per_partial, "cg_conv2d_fwd_stats: null pointer");
+    return conv2d_fwd_impl(g, nullptr, x1, x2, w, bias, y, -1, stats, stats_bytes, rows_per_partial, stream,
+                           "cg_conv2d_fwd_stats");
+}
+
+// grouped / general form: stats and amax are optional services (NULL = off)
+extern "C" int cg_conv2d_fwd_g(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2, const float* w,
+                               const float* bias, float* y, double* stats, size_t stats_bytes, int* rows_per_partial,
+                               float* amax_state, int* amax_nslots, cg_stream_t stream) {
+    CG_CHECK_ARG((amax_state == nullptr) == (amax_nslots == nullptr), "cg_conv2d_fwd_g: amax_state and amax_nslots go together");
+    fwd_amax.state = amax_state;
+    fwd_amax.nslots = 0;
+    const int rc = conv2d_fwd_impl(g, group, x1, x2, w, bias, y, -1, stats, stats_bytes, rows_per_partial, stream,
+                                   "cg_conv2d_fwd_g");
+    if (amax_nslots) *amax_nslots = rc ? 0 : fwd_amax.nslots;
+    fwd_amax.state = nullptr;
+    return rc;
+}
+
+extern "C" int cg_conv2d_fwd_tile(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
+                                  const float* bias, float* y, int tile_cfg, cg_stream_t stream) {
+    return conv2d_fwd_impl(g, nullptr, x1, x2, w, bias, y, tile_cfg, nullptr, 0, nullptr, stream, "cg_conv2d_fwd_tile");
 }
 
 // ---- split-precision forward (conv_x3.inc) --------------------------------------------------------
@@ -1504,89 +1586,91 @@ extern "C" int cg_split_f16(const float* x, void* out, size_t n, size_t lo_elems
     return CG_OK;
 }
 
-extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_lo_elems, const void* ws,
-                                size_t w_lo_elems, float w_scale, const float* x_scale_dev, const float* bias, float* y,
-                                void* y_split, size_t y_lo_elems, double* stats, size_t stats_bytes,
-                                int* rows_per_partial, int tile_cfg, float* amax_state, int* amax_nslots,
-                                cg_stream_t stream) {
-    int rc = validate_geom(g, "cg_conv2d_fwd_x3");
-    CG_CHECK_ARG((amax_state == nullptr) == (amax_nslots == nullptr), "cg_conv2d_fwd_x3: amax_state and amax_nslots go together");
+static int conv2d_fwd_x3_impl(const cg_conv_geom* g, const cg_group* group, const void* xs, size_t x_lo_elems, const void* ws,
+                              size_t w_lo_elems, float w_scale, const float* w_scale_dev, const float* x_scale_dev,
+                              const float* bias, float* y, void* y_split, size_t y_lo_elems, double* stats,
+                              size_t stats_bytes, int* rows_per_partial, int tile_cfg, float* amax_state, int* amax_nslots,
+                              cg_stream_t stream, const char* who) {
+    int rc = validate_geom(g, who);
+    CG_CHECK_ARG((amax_state == nullptr) == (amax_nslots == nullptr), "%s: amax_state and amax_nslots go together", who);
     if (amax_nslots) *amax_nslots = 0;
+    if (rows_per_partial) *rows_per_partial = 0;
     if (rc) return rc;
-    CG_CHECK_ARG(xs && ws && y && w_scale > 0.f, "cg_conv2d_fwd_x3: null pointer / bad scale");
-    CG_CHECK_ARG(!y_split || x3_lo_ok(y_lo_elems, (size_t)g->N * g->HoF * g->WoF * g->Cout * 2), "cg_conv2d_fwd_x3: bad y lo offset");
+    CG_CHECK_ARG(xs && ws && y && w_scale > 0.f, "%s: null pointer / bad scale", who);
+    Grp gr;
+    rc = grp_from(group, g->N, gr, who);
+    if (rc) return rc;
+    CG_CHECK_ARG(!y_split || x3_lo_ok(y_lo_elems, (size_t)g->N * g->HoF * g->WoF * g->Cout * 2), "%s: bad y lo offset", who);
     const int K = g->T * g->C1;
-    const int M = g->N * g->Ho * g->Wo;
+    const int Mm = (g->N / gr.n) * g->Ho * g->Wo;
     const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, w_plane = (size_t)g->Cout * K * 2;
     CG_CHECK_ARG(x3_lo_ok(x_lo_elems, x_plane) && x3_lo_ok(w_lo_elems, w_plane),
-                 "cg_conv2d_fwd_x3: lo offset does not match the operand layout (CG_X3_LO_ELEMS)");
+                 "%s: lo offset does not match the operand layout (CG_X3_LO_ELEMS)", who);
+    CG_CHECK_ARG(gr.n == 1 || (CG_X3_INTERLEAVE && gr.stride % 32 == 0),
+                 "%s: grouped launches need the interleaved operand layout and a member stride that is a multiple of 32", who);
     const size_t x_span = x3_span(x_lo_elems, x_plane), w_span = x3_span(w_lo_elems, w_plane);
     CG_CHECK_ARG(g->C2 == 0 && g->C1 % BK == 0 && x_span < (size_t)CG_OOB && w_span < (size_t)CG_OOB,
-                 "cg_conv2d_fwd_x3: needs one source with C %% 32 == 0 and operands spanning < 2 GiB");
+                 "%s: needs one source with C %% 32 == 0 and operands spanning < 2 GiB", who);
     PipeBatch b;
-    fill_class(b.c[0], g, (const float*)ws);
+    fill_class(b.c[0], g, (const float*)ws, gr.n);
     b.c[0].w_bytes = (unsigned)(w_lo_elems * 2);
     b.c[0].pad_ = (int32_t)w_span;
-    const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, M, g->C1) : tile_cfg;
-    CG_CHECK_ARG((cfg != 6 && cfg != 7) || g->C1 % 64 == 0, "cg_conv2d_fwd_x3: tile configuration %d needs C %% 64 == 0", cfg);
-    const int bm = (cfg == 3 || cfg == 10) ? 64 : ((cfg == 5 || cfg == 13) ? 256 : 128);
+    const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, (long)Mm * gr.n, g->C1) : tile_cfg;
+    CG_CHECK_ARG((cfg != 6 && cfg != 7) || g->C1 % 64 == 0, "%s: tile configuration %d needs C %% 64 == 0", who, cfg);
+    const int bm = x3_cfg_bm(cfg);
     double* st_ptr = nullptr;
-    if (rows_per_partial) {
-        *rows_per_partial = 0;
-        if (stats && g->act == CG_ACT_NONE && g->osy == 1 && g->osx == 1 && (g->Ho * g->Wo) % bm == 0 &&
-            stats_bytes >= (size_t)(M / bm) * g->Cout * 2 * sizeof(double)) {
-            st_ptr = stats;
-            *rows_per_partial = bm;
-        }
+    if (rows_per_partial && stats && g->act == CG_ACT_NONE && g->osy == 1 && g->osx == 1 && (g->Ho * g->Wo) % bm == 0 &&
+        stats_bytes >= (size_t)((size_t)Mm * gr.n / bm) * g->Cout * 2 * sizeof(double)) {
+        st_ptr = stats;
+        *rows_per_partial = bm;
     }
     hipStream_t st = cg_s(stream);
+    X3Extra ex;
+    ex.w_scale_dev = w_scale_dev;
+    ex.mb = Members{gr.n, 0, gr.stride * 4, gr.stride * 4};       // interleaved {hi, lo}: 4 bytes per element
     fwd_amax.state = amax_state;
     fwd_amax.nslots = 0;
     rc = launch_x3_cfg(cfg, b, 1, xs, bias, y, (unsigned)(x_lo_elems * 2), (unsigned)x_span, 1.0f / w_scale, x_scale_dev, st,
-                       st_ptr, y_split, y_lo_elems);
+                       st_ptr, y_split, y_lo_elems, ex);
     if (amax_nslots && !rc) *amax_nslots = fwd_amax.nslots;
     fwd_amax.state = nullptr;
     return rc;
 }
 
-// One launch for the same layer of up to four council members (same geometry, each with its own activations, weights,
-// bias and output): blockIdx.y = member.  Four times the rows per launch -> the large tiles and full waves of CUs the
-// single-member launches cannot use.  No instance-norm partials / split output / maxima yet.
-extern "C" int cg_conv2d_fwd_x3_group(int n, const cg_conv_geom* g, const void* const* x_hi, size_t x_lo_elems,
-                                      const void* const* w_hi, size_t w_lo_elems, float w_scale,
-                                      const float* const* x_scale_dev, const float* const* bias, float* const* y, int tile_cfg,
-                                      cg_stream_t stream) {
-    int rc = validate_geom(g, "cg_conv2d_fwd_x3_group");
-    if (rc) return rc;
-    CG_CHECK_ARG(n >= 1 && n <= 4 && x_hi && w_hi && y && w_scale > 0.f, "cg_conv2d_fwd_x3_group: 1..4 members, non-null tables");
-    const int K = g->T * g->C1;
-    const int M = g->N * g->Ho * g->Wo;
-    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, w_plane = (size_t)g->Cout * K * 2;
-    CG_CHECK_ARG(x3_lo_ok(x_lo_elems, x_plane) && x3_lo_ok(w_lo_elems, w_plane),
-                 "cg_conv2d_fwd_x3_group: lo offset does not match the operand layout (CG_X3_LO_ELEMS)");
-    const size_t x_span = x3_span(x_lo_elems, x_plane), w_span = x3_span(w_lo_elems, w_plane);
-    CG_CHECK_ARG(g->C2 == 0 && g->C1 % BK == 0 && x_span < (size_t)CG_OOB && w_span < (size_t)CG_OOB && g->osy == 1 && g->osx == 1,
-                 "cg_conv2d_fwd_x3_group: needs one source with C %% 32 == 0 and operands spanning < 2 GiB");
-    PipeBatch b;
-    for (int c = 0; c < n; ++c) {
-        CG_CHECK_ARG(x_hi[c] && w_hi[c] && y[c], "cg_conv2d_fwd_x3_group: null pointer for member %d", c);
-        fill_class(b.c[c], g, (const float*)w_hi[c]);
-        b.c[c].w_bytes = (unsigned)(w_lo_elems * 2);
-        b.c[c].pad_ = (int32_t)w_span;
-        b.c[c].xs = x_hi[c];
-        b.c[c].bias = bias ? bias[c] : nullptr;
-        b.c[c].y = y[c];
-        b.c[c].x_scale = x_scale_dev ? x_scale_dev[c] : nullptr;
-    }
-    const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, (long)M * n, g->C1) : tile_cfg;
-    CG_CHECK_ARG((cfg != 6 && cfg != 7) || g->C1 % 64 == 0, "cg_conv2d_fwd_x3_group: tile configuration %d needs C %% 64 == 0", cfg);
-    return launch_x3_cfg(cfg, b, n, x_hi[0], nullptr, y[0], (unsigned)(x_lo_elems * 2), (unsigned)x_span, 1.0f / w_scale, nullptr,
-                         cg_s(stream), nullptr, nullptr, 0);
+extern "C" int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* xs, size_t x_lo_elems, const void* ws,
+                                size_t w_lo_elems, float w_scale, const float* x_scale_dev, const float* bias, float* y,
+                                void* y_split, size_t y_lo_elems, double* stats, size_t stats_bytes,
+                                int* rows_per_partial, int tile_cfg, float* amax_state, int* amax_nslots,
+                                cg_stream_t stream) {
+    return conv2d_fwd_x3_impl(g, nullptr, xs, x_lo_elems, ws, w_lo_elems, w_scale, nullptr, x_scale_dev, bias, y, y_split,
+                              y_lo_elems, stats, stats_bytes, rows_per_partial, tile_cfg, amax_state, amax_nslots, stream,
+                              "cg_conv2d_fwd_x3");
+}
+
+// The same layer of `group->n` council members as ONE launch (blockIdx.z = member): member z's samples are block z of the
+// batched activation tensor, its weights / bias sit z * group->stride elements after member 0's.  w_scale_dev: the
+// device-side power-of-two scale the weights were split with (cg_split_f16_dynamic; NULL = the static w_scale only).
+extern "C" int cg_conv2d_fwd_x3_g(const cg_conv_geom* g, const cg_group* group, const void* xs, size_t x_lo_elems,
+                                  const void* ws, size_t w_lo_elems, float w_scale, const float* w_scale_dev,
+                                  const float* x_scale_dev, const float* bias, float* y, void* y_split, size_t y_lo_elems,
+                                  double* stats, size_t stats_bytes, int* rows_per_partial, int tile_cfg, float* amax_state,
+                                  int* amax_nslots, cg_stream_t stream) {
+    return conv2d_fwd_x3_impl(g, group, xs, x_lo_elems, ws, w_lo_elems, w_scale, w_scale_dev, x_scale_dev, bias, y, y_split,
+                              y_lo_elems, stats, stats_bytes, rows_per_partial, tile_cfg, amax_state, amax_nslots, stream,
+                              "cg_conv2d_fwd_x3_g");
 }
 
 extern "C" int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, float* state, int nslots,
                                     cg_stream_t stream) {
-    CG_CHECK_ARG(x && out && state && n > 0 && x3_lo_ok(lo_elems, n * 2) && nslots >= 0 && nslots <= CG_AMAX_MAX_SLOTS,
+    return cg_split_f16_dynamic_capped(x, out, n, lo_elems, state, nslots, 0.f, stream);
+}
+
+// max_scale > 0: never scale UP by more than this power of two (weights: 2^10 keeps the small-weight regime of the
+// static CG_X3_WSCALE; larger magnitudes get the smaller scale that keeps their hi halves finite)
+extern "C" int cg_split_f16_dynamic_capped(const float* x, void* out, size_t n, size_t lo_elems, float* state, int nslots,
+                                           float max_scale, cg_stream_t stream) {
+    CG_CHECK_ARG(x && out && state && n > 0 && x3_lo_ok(lo_elems, n * 2) && nslots >= 0 && nslots <= CG_AMAX_MAX_SLOTS &&
+                     max_scale >= 0.f,
                  "cg_split_f16_dynamic: bad args");
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
@@ -1598,41 +1682,45 @@ extern "C" int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t 
         CG_LAUNCH_CHECK("amax_kernel");
     }
     hipLaunchKernelGGL(split_f16_dyn_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)out, n, lo_elems, state,
-                       nslots);
+                       nslots, max_scale);
     CG_LAUNCH_CHECK("split_f16_dyn_kernel");
     return CG_OK;
 }
 
-extern "C" int cg_conv2d_fwd_tile(const cg_conv_geom* g, const float* x1, const float* x2, const float* w,
-                                  const float* bias, float* y, int tile_cfg, cg_stream_t stream) {
-    return conv2d_fwd_impl(g, x1, x2, w, bias, y, tile_cfg, stream);
-}
-
-extern "C" size_t cg_conv2d_wgrad_workspace(const cg_conv_geom* g) {
-    if (!g || g->T < 1 || g->T > CG_MAX_TAPS) return 0;
-    WgradPlan p = plan_wgrad(g);
+// ---- weight gradient -----------------------------------------------------------------------------------------------
+static size_t wgrad_workspace(const cg_conv_geom* g, int nmember) {
+    if (!g || g->T < 1 || g->T > CG_MAX_TAPS || nmember < 1 || g->N % nmember) return 0;
+    WgradPlan p = plan_wgrad(g, nmember);
     const size_t K = (size_t)g->T * (g->C1 + g->C2);
-    return (size_t)p.splits * ((size_t)g->Cout * K + g->Cout) * sizeof(float);
+    return (size_t)nmember * p.splits * ((size_t)g->Cout * K + g->Cout) * sizeof(float);
+}
+extern "C" size_t cg_conv2d_wgrad_workspace(const cg_conv_geom* g) { return wgrad_workspace(g, 1); }
+extern "C" size_t cg_conv2d_wgrad_workspace_g(const cg_conv_geom* g, const cg_group* group) {
+    return wgrad_workspace(g, group ? group->n : 1);
 }
 
-extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const float* x2, const float* dz, float* dw,
-                               float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
-    int rc = validate_geom(g, "cg_conv2d_wgrad");
+static int conv2d_wgrad_impl(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2, const float* dz,
+                             float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream,
+                             const char* who) {
+    int rc = validate_geom(g, who);
     if (rc) return rc;
-    CG_CHECK_ARG(x1 && dz && dw, "cg_conv2d_wgrad: null pointer");
-    CG_CHECK_ARG(g->C2 == 0 || x2, "cg_conv2d_wgrad: C2 > 0 needs x2");
-    const size_t need = cg_conv2d_wgrad_workspace(g);
-    if (!ws || ws_bytes < need) return cg_set_error(CG_ERR_WORKSPACE, "cg_conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
+    CG_CHECK_ARG(x1 && dz && dw, "%s: null pointer", who);
+    CG_CHECK_ARG(g->C2 == 0 || x2, "%s: C2 > 0 needs x2", who);
+    Grp gr;
+    rc = grp_from(group, g->N, gr, who);
+    if (rc) return rc;
+    const size_t need = wgrad_workspace(g, gr.n);
+    if (!ws || ws_bytes < need) return cg_set_error(CG_ERR_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, need);
     const int Ct = g->C1 + g->C2;
     const int K = g->T * Ct;
-    const int M = g->N * g->Ho * g->Wo;
+    const int M = (g->N / gr.n) * g->Ho * g->Wo;
     hipStream_t st = cg_s(stream);
-    WgradPlan p = plan_wgrad(g);
+    WgradPlan p = plan_wgrad(g, gr.n);
     float* part = (float*)ws;
     const int want_bias = dbias != nullptr;
-#define WG(BM_, BN_, WM_, WN_) rc = launch_wgrad<BM_, BN_, WM_, WN_>(g, p, x1, x2, dz, part, M, K, want_bias, st)
-#define WGP(BM_, BN_, WM_, WN_) rc = launch_wgrad_pipe<BM_, BN_, WM_, WN_>(g, p, x1, dz, part, M, K, want_bias, st)
-    if (wgrad_pipe_ok(g, p, M) && !cg_wgrad_force_legacy) {
+#define WG(BM_, BN_, WM_, WN_) rc = launch_wgrad<BM_, BN_, WM_, WN_>(g, p, x1, x2, dz, part, M, K, want_bias, st, gr.n)
+#define WGP(BM_, BN_, WM_, WN_) rc = launch_wgrad_pipe<BM_, BN_, WM_, WN_>(g, p, x1, dz, part, M, K, want_bias, st, gr.n)
+    if (wgrad_pipe_ok(g, p) && !cg_wgrad_force_legacy) {
         if (p.bm == 128 && p.bn == 128) WGP(128, 128, 64, 32);   // 8 waves
         else if (p.bm == 128 && p.bn == 64) WGP(128, 64, 64, 32);
         else if (p.bm == 64 && p.bn == 64) WGP(64, 64, 32, 32);
@@ -1644,23 +1732,21 @@ extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const flo
     else if (p.bm == 64 && p.bn == 128) WG(64, 128, 32, 64);
     else if (p.bm == 64 && p.bn == 64) WG(64, 64, 32, 32);
     else if (p.bm == 32 && p.bn == 128) WG(32, 128, 32, 32);
-    else return cg_set_error(CG_ERR_ARG, "cg_conv2d_wgrad: no tile for %dx%d", p.bm, p.bn);
+    else return cg_set_error(CG_ERR_ARG, "%s: no tile for %dx%d", who, p.bm, p.bn);
 #undef WG
 #undef WGP
     if (rc) return rc;
-    const size_t nw = (size_t)g->Cout * K;
-    const size_t n = nw + (want_bias ? g->Cout : 0);
-    if (p.splits >= 128)
-        hipLaunchKernelGGL(splitk_reduce_kernel<64>, dim3(cg_div_up(n * 64, 256)), dim3(256), 0, st, (const float*)part, dw,
-                           dbias, nw, g->Cout, p.splits, accumulate);
-    else if (p.splits >= 24)
-        hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(cg_div_up(n * 8, 256)), dim3(256), 0, st, (const float*)part, dw, dbias,
-                           nw, g->Cout, p.splits, accumulate);
-    else
-        hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cg_div_up(n, 256)), dim3(256), 0, st, (const float*)part, dw, dbias,
-                           nw, g->Cout, p.splits, accumulate);
-    CG_LAUNCH_CHECK("splitk_reduce_kernel");
-    return CG_OK;
+    return launch_splitk_reduce(part, dw, dbias, (size_t)g->Cout * K, g->Cout, p.splits, accumulate, gr, st);
+}
+
+extern "C" int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const float* x2, const float* dz, float* dw,
+                               float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
+    return conv2d_wgrad_impl(g, nullptr, x1, x2, dz, dw, dbias, accumulate, ws, ws_bytes, stream, "cg_conv2d_wgrad");
+}
+extern "C" int cg_conv2d_wgrad_g(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2,
+                                 const float* dz, float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                                 cg_stream_t stream) {
+    return conv2d_wgrad_impl(g, group, x1, x2, dz, dw, dbias, accumulate, ws, ws_bytes, stream, "cg_conv2d_wgrad_g");
 }
 
 // split-precision weight gradient (conv_x3.inc): x and dz arrive as {hi, lo} fp16 planes with their power-of-two
@@ -1669,10 +1755,10 @@ namespace {
 template <int BM, int BN, int WM, int WN>
 int launch_wgrad_x3(const cg_conv_geom* g, const WgradPlan& p, const void* xs, size_t x_lo, const float* x_scale,
                     const void* dzs, size_t dz_lo, const float* dz_scale, float* out, int M, int K, int want_bias,
-                    hipStream_t st) {
-    dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits), block((BM / WM) * (BN / WN) * 64);
-    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)M * g->Cout * 2;
-    ProfScope prof(5, BM, BN, true, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
+                    hipStream_t st, int nmember) {
+    dim3 grid(p.tiles_m * p.tiles_n, nmember, p.splits), block((BM / WM) * (BN / WN) * 64);
+    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)g->N * g->Ho * g->Wo * g->Cout * 2;
+    ProfScope prof(5, BM, BN, true, 2.0 * (double)M * nmember * (double)g->Cout * (double)K, st, g, nmember);
     hipLaunchKernelGGL((conv_wgrad_x3_kernel<BM, BN, WM, WN>), grid, block, 0, st, *g, xs, (unsigned)(x_lo * 2),
                        (unsigned)x3_span(x_lo, x_plane), x_scale, dzs, (unsigned)(dz_lo * 2), (unsigned)x3_span(dz_lo, dz_plane),
                        dz_scale, out, M, K, p.tiles_n, p.slices_per_split, want_bias, ilog2_exact(g->Ho * g->Wo),
@@ -1687,10 +1773,10 @@ namespace {
 template <int BM, int BN, int WM, int WN>
 int launch_wgrad_x3t(const cg_conv_geom* g, const WgradPlan& p, const void* xs, size_t x_lo, const float* x_scale,
                      const void* dzs, size_t dz_lo, const float* dz_scale, float* out, int M, int K, int want_bias,
-                     hipStream_t st) {
-    dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits), block((BM / WM) * (BN / WN) * 64);
-    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)M * g->Cout * 2;
-    ProfScope prof(5, BM, BN, true, 2.0 * (double)M * (double)g->Cout * (double)K, st, g);
+                     hipStream_t st, int nmember) {
+    dim3 grid(p.tiles_m * p.tiles_n, nmember, p.splits), block((BM / WM) * (BN / WN) * 64);
+    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)g->N * g->Ho * g->Wo * g->Cout * 2;
+    ProfScope prof(5, BM, BN, true, 2.0 * (double)M * nmember * (double)g->Cout * (double)K, st, g, nmember);
     hipLaunchKernelGGL((conv_wgrad_x3t_kernel<BM, BN, WM, WN>), grid, block, 0, st, *g, xs, (unsigned)x3_span(x_lo, x_plane),
                        x_scale, dzs, (unsigned)x3_span(dz_lo, dz_plane), dz_scale, out, M, K, p.tiles_n, p.slices_per_split,
                        want_bias, ilog2_exact(g->Ho * g->Wo), ilog2_exact(g->Wo));
@@ -1705,40 +1791,45 @@ static bool wgrad_x3_use_tr() {
     return on;
 }
 
-extern "C" int cg_conv2d_wgrad_x3_ok(const cg_conv_geom* g) {
-    if (!g || g->T < 1 || g->T > CG_MAX_TAPS) return 0;
-    const int M = g->N * g->Ho * g->Wo;
-    WgradPlan p = plan_wgrad(g);
-    return wgrad_pipe_ok(g, p, M) && (g->Cout & 31) == 0 && (g->C1 & 31) == 0;
+static int wgrad_x3_ok(const cg_conv_geom* g, int nmember) {
+    if (!g || g->T < 1 || g->T > CG_MAX_TAPS || nmember < 1 || g->N % nmember) return 0;
+    WgradPlan p = plan_wgrad(g, nmember);
+    return wgrad_pipe_ok(g, p) && (g->Cout & 31) == 0 && (g->C1 & 31) == 0;
 }
+extern "C" int cg_conv2d_wgrad_x3_ok(const cg_conv_geom* g) { return wgrad_x3_ok(g, 1); }
+extern "C" int cg_conv2d_wgrad_x3_ok_g(const cg_conv_geom* g, const cg_group* group) { return wgrad_x3_ok(g, group ? group->n : 1); }
 
-extern "C" int cg_conv2d_wgrad_x3(const cg_conv_geom* g, const void* xs, size_t x_lo_elems, const float* x_scale_dev,
-                                  const void* dzs, size_t dz_lo_elems, const float* dz_scale_dev, float* dw, float* dbias,
-                                  int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
-    int rc = validate_geom(g, "cg_conv2d_wgrad_x3");
+static int conv2d_wgrad_x3_impl(const cg_conv_geom* g, const cg_group* group, const void* xs, size_t x_lo_elems,
+                                const float* x_scale_dev, const void* dzs, size_t dz_lo_elems, const float* dz_scale_dev,
+                                float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream,
+                                const char* who) {
+    int rc = validate_geom(g, who);
     if (rc) return rc;
-    CG_CHECK_ARG(xs && dzs && dw, "cg_conv2d_wgrad_x3: null pointer");
-    CG_CHECK_ARG(cg_conv2d_wgrad_x3_ok(g), "cg_conv2d_wgrad_x3: layer does not qualify (see cg_conv2d_wgrad_x3_ok)");
-    const size_t need = cg_conv2d_wgrad_workspace(g);
-    if (!ws || ws_bytes < need) return cg_set_error(CG_ERR_WORKSPACE, "cg_conv2d_wgrad_x3: workspace %zu < %zu", ws_bytes, need);
+    CG_CHECK_ARG(xs && dzs && dw, "%s: null pointer", who);
+    Grp gr;
+    rc = grp_from(group, g->N, gr, who);
+    if (rc) return rc;
+    CG_CHECK_ARG(wgrad_x3_ok(g, gr.n), "%s: layer does not qualify (see cg_conv2d_wgrad_x3_ok)", who);
+    const size_t need = wgrad_workspace(g, gr.n);
+    if (!ws || ws_bytes < need) return cg_set_error(CG_ERR_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, need);
     const int K = g->T * g->C1;
-    const int M = g->N * g->Ho * g->Wo;
-    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)M * g->Cout * 2;
+    const int M = (g->N / gr.n) * g->Ho * g->Wo;
+    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)g->N * g->Ho * g->Wo * g->Cout * 2;
     CG_CHECK_ARG(x3_lo_ok(x_lo_elems, x_plane) && x3_lo_ok(dz_lo_elems, dz_plane) && x3_span(x_lo_elems, x_plane) < (size_t)CG_OOB &&
                      x3_span(dz_lo_elems, dz_plane) < (size_t)CG_OOB && g->Cout % 32 == 0 && g->C1 % 32 == 0,
-                 "cg_conv2d_wgrad_x3: operand planes out of range / lo offset does not match the layout");
+                 "%s: operand planes out of range / lo offset does not match the layout", who);
     hipStream_t st = cg_s(stream);
-    WgradPlan p = plan_wgrad(g);
+    WgradPlan p = plan_wgrad(g, gr.n);
     float* part = (float*)ws;
     const int want_bias = dbias != nullptr;
 #if CG_X3_INTERLEAVE
 #define WGX(BM_, BN_, WM_, WN_)                                                                                                  \
     rc = wgrad_x3_use_tr()                                                                                                       \
-             ? launch_wgrad_x3t<BM_, BN_, WM_, WN_>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st) \
-             : launch_wgrad_x3<BM_, BN_, WM_, WN_>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st)
+             ? launch_wgrad_x3t<BM_, BN_, WM_, WN_>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st, gr.n) \
+             : launch_wgrad_x3<BM_, BN_, WM_, WN_>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st, gr.n)
 #else
 #define WGX(BM_, BN_, WM_, WN_) \
-    rc = launch_wgrad_x3<BM_, BN_, WM_, WN_>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st)
+    rc = launch_wgrad_x3<BM_, BN_, WM_, WN_>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st, gr.n)
 #endif
     if (p.bm == 128 && p.bn == 128) WGX(128, 128, 64, 32);   // 8 waves
     else if (p.bm == 128 && p.bn == 64) WGX(128, 64, 64, 32);
@@ -1746,19 +1837,20 @@ extern "C" int cg_conv2d_wgrad_x3(const cg_conv_geom* g, const void* xs, size_t 
     else WGX(64, 128, 32, 64);
 #undef WGX
     if (rc) return rc;
-    const size_t nw = (size_t)g->Cout * K;
-    const size_t n = nw + (want_bias ? g->Cout : 0);
-    if (p.splits >= 128)
-        hipLaunchKernelGGL(splitk_reduce_kernel<64>, dim3(cg_div_up(n * 64, 256)), dim3(256), 0, st, (const float*)part, dw,
-                           dbias, nw, g->Cout, p.splits, accumulate);
-    else if (p.splits >= 24)
-        hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(cg_div_up(n * 8, 256)), dim3(256), 0, st, (const float*)part, dw, dbias,
-                           nw, g->Cout, p.splits, accumulate);
-    else
-        hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cg_div_up(n, 256)), dim3(256), 0, st, (const float*)part, dw, dbias,
-                           nw, g->Cout, p.splits, accumulate);
-    CG_LAUNCH_CHECK("splitk_reduce_kernel");
-    return CG_OK;
+    return launch_splitk_reduce(part, dw, dbias, (size_t)g->Cout * K, g->Cout, p.splits, accumulate, gr, st);
+}
+
+extern "C" int cg_conv2d_wgrad_x3(const cg_conv_geom* g, const void* xs, size_t x_lo_elems, const float* x_scale_dev,
+                                  const void* dzs, size_t dz_lo_elems, const float* dz_scale_dev, float* dw, float* dbias,
+                                  int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
+    return conv2d_wgrad_x3_impl(g, nullptr, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, dw, dbias, accumulate,
+                                ws, ws_bytes, stream, "cg_conv2d_wgrad_x3");
+}
+extern "C" int cg_conv2d_wgrad_x3_g(const cg_conv_geom* g, const cg_group* group, const void* xs, size_t x_lo_elems,
+                                    const float* x_scale_dev, const void* dzs, size_t dz_lo_elems, const float* dz_scale_dev,
+                                    float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
+    return conv2d_wgrad_x3_impl(g, group, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, dw, dbias, accumulate, ws,
+                                ws_bytes, stream, "cg_conv2d_wgrad_x3_g");
 }
 
 extern "C" int cg_conv2d_wgrad_legacy(int on) {
@@ -1766,14 +1858,18 @@ extern "C" int cg_conv2d_wgrad_legacy(int on) {
     return CG_OK;
 }
 
+// Re-layout (and optionally split) of the weights of `nmember` members for the data-gradient passes: member m reads
+// w + m*w_mstride and writes out + m*out_mstride (elements)
 static int launch_transpose(const float* w, float* out, int Cout, int T, int Cin, int ci0, int nci, const TransTable& tt,
-                            int nz, hipStream_t st, bool split = false, float scale = 1.f, unsigned lo_elems = 0) {
-    dim3 grid(cg_div_up(nci, 32), cg_div_up(Cout, 32), nz);
+                            int nz, hipStream_t st, bool split, float scale, unsigned lo_elems, int nmember,
+                            long long w_mstride, long long out_mstride, const float* scale_dev) {
+    dim3 grid(cg_div_up(nci, 32), cg_div_up(Cout, 32), nz * nmember);
     if (split)
         hipLaunchKernelGGL(weight_transpose_kernel<true>, grid, dim3(256), 0, st, w, out, Cout, T, Cin, ci0, nci, tt, scale,
-                           lo_elems);
+                           lo_elems, nz, w_mstride, out_mstride, scale_dev);
     else
-        hipLaunchKernelGGL(weight_transpose_kernel<false>, grid, dim3(256), 0, st, w, out, Cout, T, Cin, ci0, nci, tt, 1.f, 0u);
+        hipLaunchKernelGGL(weight_transpose_kernel<false>, grid, dim3(256), 0, st, w, out, Cout, T, Cin, ci0, nci, tt, 1.f, 0u,
+                           nz, w_mstride, out_mstride, (const float*)nullptr);
     CG_LAUNCH_CHECK("weight_transpose_kernel");
     return CG_OK;
 }
@@ -1792,7 +1888,7 @@ extern "C" int cg_weight_transpose(const float* w, float* out, int Cout, int T, 
         tt.dst_tc[i] = i;
         tt.dst_T[i] = Tc;
     }
-    return launch_transpose(w, out, Cout, T, Cin, ci0, nci, tt, Tc, cg_s(stream));
+    return launch_transpose(w, out, Cout, T, Cin, ci0, nci, tt, Tc, cg_s(stream), false, 1.f, 0u, 1, 0, 0, nullptr);
 }
 
 // ---- data gradient of a convolution -------------------------------------------------------------
@@ -1806,7 +1902,7 @@ struct DgradPlan {
     cg_conv_geom cg[CG_MAX_TAPS];  // at most stride^2 classes; only the first ncls are valid (<= 4 batched)
     int tap_src[CG_MAX_TAPS][CG_MAX_TAPS];
     size_t w_off[CG_MAX_TAPS];
-    size_t ws_floats;
+    size_t ws_floats;              // elements of ONE member's re-laid-out weights
 };
 inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
@@ -1842,31 +1938,10 @@ int plan_dgrad(const cg_conv_geom* g, int nci, DgradPlan& p) {
         }
     return CG_OK;
 }
-}  // namespace
 
-extern "C" size_t cg_conv2d_dgrad_workspace(const cg_conv_geom* g, int nci) {
-    if (!g || g->T < 1 || g->T > CG_MAX_TAPS || nci < 1) return 0;
-    return (size_t)g->T * nci * g->Cout * sizeof(float);   // every tap belongs to exactly one class
-}
-
-extern "C" int cg_conv2d_dgrad(const cg_conv_geom* g, const float* dz, const float* w, int ci0, int nci, float* dx,
-                               void* ws, size_t ws_bytes, cg_stream_t stream) {
-    int rc = validate_geom(g, "cg_conv2d_dgrad");
-    if (rc) return rc;
-    CG_CHECK_ARG(dz && w && dx, "cg_conv2d_dgrad: null pointer");
-    const int Cin = g->C1 + g->C2;
-    CG_CHECK_ARG(ci0 >= 0 && nci >= 1 && ci0 + nci <= Cin, "cg_conv2d_dgrad: channel range [%d, %d) outside %d", ci0, ci0 + nci, Cin);
-    if (!ws || ws_bytes < cg_conv2d_dgrad_workspace(g, nci))
-        return cg_set_error(CG_ERR_WORKSPACE, "cg_conv2d_dgrad: workspace too small");
-    static thread_local DgradPlan p;
-    rc = plan_dgrad(g, nci, p);
-    if (rc) return rc;
-    hipStream_t st = cg_s(stream);
-    float* wt = (float*)ws;
-    // one launch re-lays-out the weights of every class: wt_c[ci][tc][co]
-    TransTable tt;
+void dgrad_table(const DgradPlan& p, TransTable& tt, int& nz) {
     memset(&tt, 0, sizeof(tt));
-    int nz = 0;
+    nz = 0;
     for (int c = 0; c < p.ncls; ++c)
         for (int tc = 0; tc < p.cg[c].T; ++tc, ++nz) {
             tt.src_tap[nz] = p.tap_src[c][tc];
@@ -1874,8 +1949,41 @@ extern "C" int cg_conv2d_dgrad(const cg_conv_geom* g, const float* dz, const flo
             tt.dst_tc[nz] = tc;
             tt.dst_T[nz] = p.cg[c].T;
         }
-    CG_CHECK_ARG(p.ws_floats < (size_t)0x7fffffff, "cg_conv2d_dgrad: weight tensor too large");
-    rc = launch_transpose(w, wt, g->Cout, g->T, Cin, ci0, nci, tt, nz, st);
+}
+}  // namespace
+
+static size_t dgrad_workspace(const cg_conv_geom* g, int nci, int nmember) {
+    if (!g || g->T < 1 || g->T > CG_MAX_TAPS || nci < 1 || nmember < 1) return 0;
+    return (size_t)nmember * g->T * nci * g->Cout * sizeof(float);   // every tap belongs to exactly one class
+}
+extern "C" size_t cg_conv2d_dgrad_workspace(const cg_conv_geom* g, int nci) { return dgrad_workspace(g, nci, 1); }
+extern "C" size_t cg_conv2d_dgrad_workspace_g(const cg_conv_geom* g, const cg_group* group, int nci) {
+    return dgrad_workspace(g, nci, group ? group->n : 1);
+}
+
+static int conv2d_dgrad_impl(const cg_conv_geom* g, const cg_group* group, const float* dz, const float* w, int ci0, int nci,
+                             float* dx, void* ws, size_t ws_bytes, cg_stream_t stream, const char* who) {
+    int rc = validate_geom(g, who);
+    if (rc) return rc;
+    CG_CHECK_ARG(dz && w && dx, "%s: null pointer", who);
+    Grp gr;
+    rc = grp_from(group, g->N, gr, who);
+    if (rc) return rc;
+    const int Cin = g->C1 + g->C2;
+    CG_CHECK_ARG(ci0 >= 0 && nci >= 1 && ci0 + nci <= Cin, "%s: channel range [%d, %d) outside %d", who, ci0, ci0 + nci, Cin);
+    if (!ws || ws_bytes < dgrad_workspace(g, nci, gr.n)) return cg_set_error(CG_ERR_WORKSPACE, "%s: workspace too small", who);
+    static thread_local DgradPlan p;
+    rc = plan_dgrad(g, nci, p);
+    if (rc) return rc;
+    hipStream_t st = cg_s(stream);
+    float* wt = (float*)ws;
+    // one launch re-lays-out the weights of every class (and member): wt_c[ci][tc][co]
+    TransTable tt;
+    int nz;
+    dgrad_table(p, tt, nz);
+    CG_CHECK_ARG(p.ws_floats < (size_t)0x7fffffff, "%s: weight tensor too large", who);
+    rc = launch_transpose(w, wt, g->Cout, g->T, Cin, ci0, nci, tt, nz, st, false, 1.f, 0u, gr.n, gr.stride,
+                          (long long)p.ws_floats, nullptr);
     if (rc) return rc;
     // batched pipelined launch when every class qualifies
     bool pipe = p.ncls <= 4;
@@ -1884,19 +1992,37 @@ extern "C" int cg_conv2d_dgrad(const cg_conv_geom* g, const float* dz, const flo
         pipe = pipe_ok(&p.cg[c], p.cg[c].T * p.cg[c].C1);
         m_total += (long)p.cg[c].N * p.cg[c].Ho * p.cg[c].Wo;
     }
+    const Members mb{gr.n, 0, (long long)p.ws_floats * 4, 0};
     if (pipe) {
         PipeBatch b;
-        for (int c = 0; c < p.ncls; ++c) fill_class(b.c[c], &p.cg[c], wt + p.w_off[c]);
-        const int cfg = pick_fwd_cfg(&p.cg[0], (int)(m_total > 0x7fffffffL ? 0x7fffffffL : m_total), true);
+        for (int c = 0; c < p.ncls; ++c) fill_class(b.c[c], &p.cg[c], wt + p.w_off[c], gr.n);
+        const int cfg = pick_fwd_cfg(&p.cg[0], m_total, true);
         if (cfg >= 20)
             return launch_pipe_cfg(cfg, b, p.ncls, dz, nullptr, dx,
-                                   (unsigned)((size_t)g->N * g->Ho * g->Wo * g->Cout * sizeof(float)), st);
+                                   (unsigned)((size_t)g->N * g->Ho * g->Wo * g->Cout * sizeof(float)), st, nullptr, mb);
     }
+    Grp gt;                      // the transposed weights of the members sit ws_floats apart
+    gt.n = gr.n;
+    gt.stride = (long long)p.ws_floats;
     for (int c = 0; c < p.ncls; ++c) {
-        rc = cg_conv2d_fwd(&p.cg[c], dz, nullptr, wt + p.w_off[c], nullptr, dx, stream);
+        const cg_conv_geom* cgm = &p.cg[c];
+        const int Ct = cgm->C1, K = cgm->T * Ct;
+        const int Mm = (cgm->N / gr.n) * cgm->Ho * cgm->Wo;
+        const bool fast = Ct % 32 == 0;
+        const int cfg = pick_fwd_cfg(cgm, (long)Mm * gr.n, fast && pipe_ok(cgm, K));
+        rc = launch_fwd_cfg(cfg, cgm, dz, nullptr, wt + p.w_off[c], nullptr, dx, Mm, K, fast, st, nullptr, gt);
         if (rc) return rc;
     }
     return CG_OK;
+}
+
+extern "C" int cg_conv2d_dgrad(const cg_conv_geom* g, const float* dz, const float* w, int ci0, int nci, float* dx,
+                               void* ws, size_t ws_bytes, cg_stream_t stream) {
+    return conv2d_dgrad_impl(g, nullptr, dz, w, ci0, nci, dx, ws, ws_bytes, stream, "cg_conv2d_dgrad");
+}
+extern "C" int cg_conv2d_dgrad_g(const cg_conv_geom* g, const cg_group* group, const float* dz, const float* w, int ci0,
+                                 int nci, float* dx, void* ws, size_t ws_bytes, cg_stream_t stream) {
+    return conv2d_dgrad_impl(g, group, dz, w, ci0, nci, dx, ws, ws_bytes, stream, "cg_conv2d_dgrad_g");
 }
 
 extern "C" int cg_act_bwd_split(const float* dy, const float* y, size_t n, int act, void* out, size_t lo_elems,
@@ -1915,51 +2041,90 @@ extern "C" int cg_act_bwd_split(const float* dy, const float* y, size_t n, int a
     return CG_OK;
 }
 
-// split-precision data-gradient: dz arrives as {hi, lo} fp16 planes with its device-side scale (cg_split_f16_dynamic);
-// the weights are re-laid-out AND split (scaled by CG_X3_WSCALE) by one launch into `ws`
-extern "C" int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, size_t dz_lo_elems,
-                                  const float* dz_scale_dev, const float* w, int ci0, int nci, float* dx, void* ws,
-                                  size_t ws_bytes, cg_stream_t stream) {
-    int rc = validate_geom(g, "cg_conv2d_dgrad_x3");
+// ---- split-precision data-gradient ---------------------------------------------------------------------------------
+// Two steps, so that the re-laid-out weights can be cached across the many launches that use one weight version:
+//   cg_conv2d_dgrad_x3_prep:  w (fp32, [Cout][T][Cin]) of every member -> {hi, lo} fp16 planes of scale*w in the per-class
+//                             [ci][tc][co] layout the data-gradient kernel reads, member m at wt + m * wt_elems elements
+//                             (cg_conv2d_dgrad_x3_wt_elems; 4 bytes per element).  scale = w_scale, or the device-side
+//                             value *w_scale_dev when given.
+//   cg_conv2d_dgrad_x3_run:   dx from dz ({hi, lo} planes with its device-side scale) and the prepared weights.
+// cg_conv2d_dgrad_x3 = both, with the prepared weights in the caller's workspace.
+extern "C" size_t cg_conv2d_dgrad_x3_wt_elems(const cg_conv_geom* g, int nci) {
+    if (!g || g->T < 1 || g->T > CG_MAX_TAPS || nci < 1) return 0;
+    return (size_t)g->T * nci * g->Cout;
+}
+
+static int dgrad_x3_checks(const cg_conv_geom* g, const cg_group* group, int ci0, int nci, Grp& gr, DgradPlan& p, const char* who) {
+    int rc = validate_geom(g, who);
     if (rc) return rc;
-    CG_CHECK_ARG(dz_split && w && dx && dz_scale_dev, "cg_conv2d_dgrad_x3: null pointer");
+    rc = grp_from(group, g->N, gr, who);
+    if (rc) return rc;
     const int Cin = g->C1 + g->C2;
-    CG_CHECK_ARG(ci0 >= 0 && nci >= 1 && ci0 + nci <= Cin, "cg_conv2d_dgrad_x3: channel range outside %d", Cin);
-    CG_CHECK_ARG(g->Cout % BK == 0, "cg_conv2d_dgrad_x3: Cout %% 32 != 0");
-    if (!ws || ws_bytes < cg_conv2d_dgrad_workspace(g, nci))
-        return cg_set_error(CG_ERR_WORKSPACE, "cg_conv2d_dgrad_x3: workspace too small");
-    static thread_local DgradPlan p;
+    CG_CHECK_ARG(ci0 >= 0 && nci >= 1 && ci0 + nci <= Cin, "%s: channel range outside %d", who, Cin);
+    CG_CHECK_ARG(g->Cout % BK == 0, "%s: Cout %% 32 != 0", who);
     rc = plan_dgrad(g, nci, p);
     if (rc) return rc;
-    CG_CHECK_ARG(p.ncls <= 4, "cg_conv2d_dgrad_x3: stride %d has more than 4 output classes", g->stride);
-    hipStream_t st = cg_s(stream);
+    CG_CHECK_ARG(p.ncls <= 4, "%s: stride %d has more than 4 output classes", who, g->stride);
+    CG_CHECK_ARG(4 * p.ws_floats < (size_t)CG_OOB, "%s: weight tensor too large", who);
+    CG_CHECK_ARG(gr.n == 1 || (CG_X3_INTERLEAVE && p.ws_floats % 32 == 0), "%s: grouped launches need the interleaved layout", who);
+    return CG_OK;
+}
+
+extern "C" int cg_conv2d_dgrad_x3_prep(const cg_conv_geom* g, const cg_group* group, const float* w, int ci0, int nci,
+                                       float w_scale, const float* w_scale_dev, void* wt, size_t wt_bytes,
+                                       cg_stream_t stream) {
+    static thread_local DgradPlan p;
+    Grp gr;
+    int rc = dgrad_x3_checks(g, group, ci0, nci, gr, p, "cg_conv2d_dgrad_x3_prep");
+    if (rc) return rc;
+    CG_CHECK_ARG(w && wt && w_scale > 0.f, "cg_conv2d_dgrad_x3_prep: null pointer / bad scale");
+    if (wt_bytes < (size_t)gr.n * p.ws_floats * 4) return cg_set_error(CG_ERR_WORKSPACE, "cg_conv2d_dgrad_x3_prep: buffer too small");
     TransTable tt;
-    memset(&tt, 0, sizeof(tt));
-    int nz = 0;
-    for (int c = 0; c < p.ncls; ++c)
-        for (int tc = 0; tc < p.cg[c].T; ++tc, ++nz) {
-            tt.src_tap[nz] = p.tap_src[c][tc];
-            tt.dst_base[nz] = (int32_t)p.w_off[c];
-            tt.dst_tc[nz] = tc;
-            tt.dst_T[nz] = p.cg[c].T;
-        }
+    int nz;
+    dgrad_table(p, tt, nz);
+    const size_t wt_lo = CG_X3_INTERLEAVE ? (size_t)CG_X3_LO_ELEMS : p.ws_floats;      // lo offset of the re-laid-out weights
+    CG_CHECK_ARG(gr.n == 1 || CG_X3_INTERLEAVE, "cg_conv2d_dgrad_x3_prep: grouped launches need the interleaved layout");
+    return launch_transpose(w, (float*)wt, g->Cout, g->T, g->C1 + g->C2, ci0, nci, tt, nz, cg_s(stream), true, w_scale,
+                            (unsigned)wt_lo, gr.n, gr.stride, (long long)p.ws_floats, w_scale_dev);
+}
+
+extern "C" int cg_conv2d_dgrad_x3_run(const cg_conv_geom* g, const cg_group* group, const void* dz_split, size_t dz_lo_elems,
+                                      const float* dz_scale_dev, const void* wt, float w_scale, const float* w_scale_dev,
+                                      int ci0, int nci, float* dx, cg_stream_t stream) {
+    static thread_local DgradPlan p;
+    Grp gr;
+    int rc = dgrad_x3_checks(g, group, ci0, nci, gr, p, "cg_conv2d_dgrad_x3_run");
+    if (rc) return rc;
+    CG_CHECK_ARG(dz_split && wt && dx && dz_scale_dev && w_scale > 0.f, "cg_conv2d_dgrad_x3_run: null pointer / bad scale");
     const size_t wt_elems = p.ws_floats;          // one fp16 plane = as many elements as the fp32 layout had floats
     const size_t dz_plane = (size_t)g->N * g->Ho * g->Wo * g->Cout * 2;
-    CG_CHECK_ARG(x3_lo_ok(dz_lo_elems, dz_plane) && x3_span(dz_lo_elems, dz_plane) < (size_t)CG_OOB && 4 * wt_elems < (size_t)CG_OOB,
-                 "cg_conv2d_dgrad_x3: operand planes out of range / lo offset does not match the layout");
-    const size_t wt_lo = CG_X3_INTERLEAVE ? (size_t)CG_X3_LO_ELEMS : wt_elems;      // lo offset of the re-laid-out weights
-    rc = launch_transpose(w, (float*)ws, g->Cout, g->T, Cin, ci0, nci, tt, nz, st, true, CG_X3_WSCALE, (unsigned)wt_lo);
-    if (rc) return rc;
+    CG_CHECK_ARG(x3_lo_ok(dz_lo_elems, dz_plane) && x3_span(dz_lo_elems, dz_plane) < (size_t)CG_OOB,
+                 "cg_conv2d_dgrad_x3_run: operand planes out of range / lo offset does not match the layout");
+    const size_t wt_lo = CG_X3_INTERLEAVE ? (size_t)CG_X3_LO_ELEMS : wt_elems;
     PipeBatch b;
     long m_total = 0;
     for (int c = 0; c < p.ncls; ++c) {
-        fill_class(b.c[c], &p.cg[c], (const float*)((const _Float16*)ws + cg_il(p.w_off[c])));     // class sizes: multiples of 32
+        fill_class(b.c[c], &p.cg[c], (const float*)((const _Float16*)wt + cg_il(p.w_off[c])), gr.n);   // class sizes: multiples of 32
         b.c[c].w_bytes = (unsigned)(wt_lo * 2);                                                     // lo offset
         b.c[c].pad_ = (int32_t)(4 * wt_elems - 2 * cg_il(p.w_off[c]));                             // span from this class's base
-        m_total += b.c[c].M;
+        m_total += (long)b.c[c].M * gr.n;
     }
+    X3Extra ex;
+    ex.w_scale_dev = w_scale_dev;
+    ex.mb = Members{gr.n, 0, (long long)wt_elems * 4, 0};
     return launch_x3_cfg(pick_x3_cfg(nci, m_total, g->Cout), b, p.ncls, dz_split, nullptr, dx, (unsigned)(dz_lo_elems * 2),
-                         (unsigned)x3_span(dz_lo_elems, dz_plane), 1.0f / CG_X3_WSCALE, dz_scale_dev, st, nullptr, nullptr, 0);
+                         (unsigned)x3_span(dz_lo_elems, dz_plane), 1.0f / w_scale, dz_scale_dev, cg_s(stream), nullptr, nullptr, 0,
+                         ex);
+}
+
+extern "C" int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, size_t dz_lo_elems,
+                                  const float* dz_scale_dev, const float* w, int ci0, int nci, float* dx, void* ws,
+                                  size_t ws_bytes, cg_stream_t stream) {
+    if (!ws || ws_bytes < cg_conv2d_dgrad_workspace(g, nci))
+        return cg_set_error(CG_ERR_WORKSPACE, "cg_conv2d_dgrad_x3: workspace too small");
+    int rc = cg_conv2d_dgrad_x3_prep(g, nullptr, w, ci0, nci, CG_X3_WSCALE, nullptr, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return cg_conv2d_dgrad_x3_run(g, nullptr, dz_split, dz_lo_elems, dz_scale_dev, ws, CG_X3_WSCALE, nullptr, ci0, nci, dx, stream);
 }
 
 extern "C" int cg_x3_interleaved(void) { return CG_X3_INTERLEAVE; }

@@ -132,8 +132,8 @@ class FlatAdam(torch.optim.Optimizer):
                 continue
             off = f["offs"][i]
             state[i] = {"step": torch.tensor(float(self._steps[i])),
-                        "exp_avg": _phys_view(f["m"], off, tuple(p.shape)).clone(),
-                        "exp_avg_sq": _phys_view(f["v"], off, tuple(p.shape)).clone()}
+                        "exp_avg": _phys_view(f["m"], off, tuple(p.shape)).clone(memory_format=torch.contiguous_format),
+                        "exp_avg_sq": _phys_view(f["v"], off, tuple(p.shape)).clone(memory_format=torch.contiguous_format)}
         groups = []
         for g in self.param_groups:
             gg = {k: v for k, v in g.items() if k != "params"}
