@@ -220,7 +220,10 @@ def main():
                                          "and weight-gradient convolution with >= 32 channels; 3/6-channel first layers and "
                                          "<= 32-channel heads: fp32 MFMA"
                                          if trainer._split_fwd else "fp32 MFMA everywhere"),
-                   "member_streams": len(trainer._streams) or 1},
+                   "members_per_launch": (len(trainer._groups[1][0]) if trainer._groups else 1),
+                   "execution": ("member-batched: the local members' same layer runs as ONE launch (ops.members, "
+                                 "optim.ParamPool); CG_GROUP=1 walks the members one by one on %d HIP stream(s)"
+                                 % (len(trainer._streams) or 1))},
     }
 
     if rank == 0 and world == 1:

@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     const int z = blockIdx.z - member * nz;
     w += (long long)member * w_mstride;
     out += (long long)member * out_mstride;
-    if (SPLIT && scale_dev) scale = scale_dev[0];
+    if (SPLIT && scale_dev) scale *= scale_dev[0];
     const int tap = tab[z], base = tab[CG_MAX_TAPS + z], tc = tab[2 * CG_MAX_TAPS + z], Tc = tab[3 * CG_MAX_TAPS + z];
     const int cib = blockIdx.x * 32, cob = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8

@@ -190,14 +190,17 @@ __global__ void mask_blend_bwd_kernel(const float* __restrict__ nx, const float*
 }
 
 // ---- LSGAN, networks.py:64,90,166,194 ------------------------------------------------------------
+// One block per council member (blockIdx.x): nb = samples of ONE member, whose rows follow the previous member's.
 __global__ __launch_bounds__(256) void lsgan_fwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
                                                         const float* __restrict__ wt, int nb, int hw, int group,
                                                         float* __restrict__ loss, int accumulate) {
     __shared__ double red[4];
     double s = 0.0;
     const int total = nb * hw;
+    const int s0 = (int)blockIdx.x * nb;
+    out += (size_t)s0 * hw;
     for (int i = threadIdx.x; i < total; i += 256) {
-        const int sidx = i / hw;
+        const int sidx = s0 + i / hw;
         const float d = out[i] - tgt[sidx];
         s += (double)wt[sidx] * (double)d * (double)d;
     }
@@ -206,26 +209,29 @@ __global__ __launch_bounds__(256) void lsgan_fwd_kernel(const float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         const double t = (red[0] + red[1] + red[2] + red[3]) / ((double)group * hw);
-        loss[0] = (accumulate ? loss[0] : 0.f) + (float)t;
+        loss[blockIdx.x] = (accumulate ? loss[blockIdx.x] : 0.f) + (float)t;
     }
 }
 __global__ void lsgan_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
                                  const float* __restrict__ wt, const float* __restrict__ gscale, int nb, int hw,
-                                 int group, float* __restrict__ d_out) {
-    const size_t total = (size_t)nb * hw;
-    const float gs = gscale[0] * 2.f / ((float)group * (float)hw);
+                                 int group, float* __restrict__ d_out, int nmember) {
+    const size_t total = (size_t)nb * nmember * hw;      // nb = samples of ONE member; gscale has one entry per member
+    const float k = 2.f / ((float)group * (float)hw);
     GRID_STRIDE(i, total) {
         const int sidx = (int)(i / hw);
-        d_out[i] = gs * wt[sidx] * (out[i] - tgt[sidx]);
+        d_out[i] = gscale[sidx / nb] * k * wt[sidx] * (out[i] - tgt[sidx]);
     }
 }
 
 // ---- focus-loss criteria, trainer_council.py:230-250 ------------------------------------------
 constexpr int FOCUS_BLOCKS = 256;
 // stage 1: FOCUS_BLOCKS partial triples (fp64); stage 2: one wave adds them in a fixed order
+// blockIdx.y = council member (its `total` mask elements follow the previous member's; partials likewise)
 __global__ __launch_bounds__(256) void focus_partial_kernel(const float* __restrict__ mask, int H, int W, int k,
                                                             size_t total, float center, float eps,
                                                             double* __restrict__ part) {
+    mask += (size_t)blockIdx.y * total;
+    part += (size_t)blockIdx.y * gridDim.x * 3;
     __shared__ double red[3][4];
     double a = 0.0, b = 0.0, t = 0.0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -254,6 +260,8 @@ __global__ __launch_bounds__(256) void focus_partial_kernel(const float* __restr
 }
 __global__ __launch_bounds__(64) void focus_final_kernel(const double* __restrict__ part, int nblocks,
                                                          float* __restrict__ sums) {
+    part += (size_t)blockIdx.x * nblocks * 3;       // blockIdx.x = council member
+    sums += blockIdx.x * 3;
     for (int q = 0; q < 3; ++q) {
         double s = 0.0;
         for (int b = threadIdx.x; b < nblocks; b += 64) s += part[(size_t)b * 3 + q];
@@ -263,7 +271,9 @@ __global__ __launch_bounds__(64) void focus_final_kernel(const double* __restric
 }
 __global__ void focus_total_kernel(const float* __restrict__ sums, float numel, float w_zo, float w_total, float w_tv,
                                    int use_abs, int use_square, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    sums += blockIdx.x * 3;                                 // blockIdx.x = council member
+    out += blockIdx.x * 4;
     const float zo = sums[0] / numel;                       // trainer_council.py:230-231
     float small = 0.f;
     if (use_abs) small += fabsf(sums[1]) / numel;           // :245-246
@@ -279,9 +289,13 @@ __global__ void focus_bwd_kernel(const float* __restrict__ mask, const float* __
                                  const float* __restrict__ gscale, int N, int H, int W, int k, float center, float eps,
                                  float w_zo, float w_total, float w_tv, int use_abs, int use_square,
                                  float* __restrict__ d_mask) {
+    // N = samples of ONE council member; blockIdx.y = member (its mask block, its three sums, its upstream gradient)
     const size_t total = (size_t)N * H * W * k;
     const float numel = (float)total;
-    const float gs = gscale[0];
+    mask += (size_t)blockIdx.y * total;
+    d_mask += (size_t)blockIdx.y * total;
+    sums += blockIdx.y * 3;
+    const float gs = gscale[blockIdx.y];
     // mask_small: abs -> |sum m|/numel ; square -> (sum m/numel)^2   (trainer_council.py:242-246)
     float dsmall = 0.f;
     if (use_abs) dsmall += sgn(sums[1]) / numel;
@@ -336,8 +350,10 @@ __global__ void l1_mean_bwd_kernel(const float* __restrict__ a, const float* __r
 // ---- torch.optim.Adam (L2 weight decay), trainer_council.py:170-179 ----------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, size_t n, float beta1, float beta2, float eps, float wd,
-                            float step_size, float bc2_sqrt) {
+                            float step_size, float bc2_sqrt, long long mstride) {
     const float w1 = 1.f - beta1;
+    const long long mo = (long long)blockIdx.y * mstride;       // blockIdx.y = council member (same run of its pool slice)
+    p += mo; g += mo; m += mo; v += mo;
     GRID_STRIDE(i, n) {
         const float pi = p[i];
         const float gi = g[i] + wd * pi;                      // grad.add(param, alpha=weight_decay)
@@ -361,10 +377,42 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int32_t*
     }
 }
 
+// out[i] = (idx[i] >= 0 ? src_a[idx[i]] : src_b[-idx[i] - 1]) along dim 0: the discriminator batches [own fake | real],
+// [own translation | colleagues' translations] are assembled from two tensors without a torch.cat
+__global__ void gather_rows2_kernel(const float* __restrict__ a, const float* __restrict__ b, const int32_t* __restrict__ idx,
+                                    float* __restrict__ out, int nidx, size_t row4) {
+    const size_t total = (size_t)nidx * row4;      // float4 units (row_elems % 4 == 0)
+    GRID_STRIDE(i, total) {
+        const size_t r = i / row4, e = i - r * row4;
+        const int k = idx[r];
+        const float4* src = reinterpret_cast<const float4*>(k >= 0 ? a : b) + (size_t)(k >= 0 ? k : -k - 1) * row4;
+        reinterpret_cast<float4*>(out)[i] = src[e];
+    }
+}
+
+// per member m: council[m] = council_w * (w_match ? w_match[m] : 1) * lc[m];  total[m] = focus[m] + gan_w * adv[m] +
+// council[m];  gcouncil[m] = council_w * w_match[m] (the upstream gradient of lc).  NULL terms count as zero.
+__global__ void gen_total_kernel(const float* __restrict__ focus, const float* __restrict__ adv, const float* __restrict__ lc,
+                                 const float* __restrict__ w_match, float gan_w, float council_w, float* __restrict__ total,
+                                 float* __restrict__ council, float* __restrict__ gcouncil, int n) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    const float wm = w_match ? w_match[m] : 1.f;
+    const float c = lc ? council_w * wm * lc[m] : 0.f;
+    if (council) council[m] = c;
+    if (gcouncil) gcouncil[m] = council_w * wm;
+    total[m] = (focus ? focus[m * 4] : 0.f) + (adv ? gan_w * adv[m] : 0.f) + c;
+}
+
 // ring[pos % n] = value ; optional w = mean(ring_a) / mean(ring_b)  (trainer_council.py:518-524,576-581)
+// blockIdx.x = council member: rings [member][n], value / w_out one entry per member
 __global__ void ring_kernel(float* __restrict__ ring_a, float* __restrict__ ring_b, int n, int pos,
                             const float* __restrict__ value, float* __restrict__ w_out, int push_b) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    ring_a += (size_t)blockIdx.x * n;
+    if (ring_b) ring_b += (size_t)blockIdx.x * n;
+    value += blockIdx.x;
+    if (w_out) w_out += blockIdx.x;
     if (push_b)
         ring_b[pos % n] = value[0];
     else
@@ -493,48 +541,80 @@ extern "C" int cg_mask_blend_bwd(const float* new_x, const float* im_in, const f
     return CG_OK;
 }
 
-extern "C" int cg_lsgan_fwd(const float* out, const float* tgt, const float* wt, int nb, int hw, int group,
-                            float* loss, int accumulate, cg_stream_t stream) {
-    CG_CHECK_ARG(out && tgt && wt && loss && nb > 0 && hw > 0 && group > 0, "cg_lsgan_fwd: bad args");
-    hipLaunchKernelGGL(lsgan_fwd_kernel, dim3(1), dim3(256), 0, cg_s(stream), out, tgt, wt, nb, hw, group, loss, accumulate);
+// grouped forms: nb = samples of ALL members (member m owns samples [m*nb/nmember, (m+1)*nb/nmember)); loss / gscale have
+// one entry per member.  A member's value does not depend on the other members in the launch.
+extern "C" int cg_lsgan_fwd_g(const float* out, const float* tgt, const float* wt, int nb, int hw, int group, int nmember,
+                              float* loss, int accumulate, cg_stream_t stream) {
+    CG_CHECK_ARG(out && tgt && wt && loss && nb > 0 && hw > 0 && group > 0 && nmember > 0 && nb % nmember == 0,
+                 "cg_lsgan_fwd: bad args");
+    hipLaunchKernelGGL(lsgan_fwd_kernel, dim3(nmember), dim3(256), 0, cg_s(stream), out, tgt, wt, nb / nmember, hw, group, loss,
+                       accumulate);
     CG_LAUNCH_CHECK("lsgan_fwd_kernel");
     return CG_OK;
 }
+extern "C" int cg_lsgan_bwd_g(const float* out, const float* tgt, const float* wt, const float* gscale, int nb, int hw,
+                              int group, int nmember, float* d_out, cg_stream_t stream) {
+    CG_CHECK_ARG(out && tgt && wt && gscale && d_out && nb > 0 && hw > 0 && group > 0 && nmember > 0 && nb % nmember == 0,
+                 "cg_lsgan_bwd: bad args");
+    EW_LAUNCH(lsgan_bwd_kernel, (size_t)nb * hw, out, tgt, wt, gscale, nb / nmember, hw, group, d_out, nmember);
+}
+extern "C" int cg_lsgan_fwd(const float* out, const float* tgt, const float* wt, int nb, int hw, int group,
+                            float* loss, int accumulate, cg_stream_t stream) {
+    return cg_lsgan_fwd_g(out, tgt, wt, nb, hw, group, 1, loss, accumulate, stream);
+}
 extern "C" int cg_lsgan_bwd(const float* out, const float* tgt, const float* wt, const float* gscale, int nb, int hw,
                             int group, float* d_out, cg_stream_t stream) {
-    CG_CHECK_ARG(out && tgt && wt && gscale && d_out && nb > 0 && hw > 0 && group > 0, "cg_lsgan_bwd: bad args");
-    EW_LAUNCH(lsgan_bwd_kernel, (size_t)nb * hw, out, tgt, wt, gscale, nb, hw, group, d_out);
+    return cg_lsgan_bwd_g(out, tgt, wt, gscale, nb, hw, group, 1, d_out, stream);
 }
 
-extern "C" size_t cg_focus_workspace(void) { return (size_t)FOCUS_BLOCKS * 3 * sizeof(double); }
-extern "C" int cg_focus_sums(const float* mask, int N, int H, int W, int k, float center, float eps, float* sums,
-                             void* ws, size_t ws_bytes, cg_stream_t stream) {
-    CG_CHECK_ARG(mask && sums && N > 0 && H > 0 && W > 0 && k > 0, "cg_focus_sums: bad args");
-    if (!ws || ws_bytes < cg_focus_workspace()) return cg_set_error(CG_ERR_WORKSPACE, "cg_focus_sums: workspace too small");
-    const size_t total = (size_t)N * H * W * k;
+extern "C" size_t cg_focus_workspace(void) { return (size_t)FOCUS_BLOCKS * 3 * sizeof(double); }     // per member
+// grouped forms: N = samples of ALL members; sums [nmember][3], out [nmember][4], gscale [nmember]; ws: nmember * cg_focus_workspace()
+extern "C" int cg_focus_sums_g(const float* mask, int N, int H, int W, int k, int nmember, float center, float eps,
+                               float* sums, void* ws, size_t ws_bytes, cg_stream_t stream) {
+    CG_CHECK_ARG(mask && sums && N > 0 && H > 0 && W > 0 && k > 0 && nmember > 0 && N % nmember == 0, "cg_focus_sums: bad args");
+    if (!ws || ws_bytes < (size_t)nmember * cg_focus_workspace())
+        return cg_set_error(CG_ERR_WORKSPACE, "cg_focus_sums: workspace too small");
+    const size_t total = (size_t)(N / nmember) * H * W * k;
     size_t nb = (total + 255) / 256;
     if (nb > FOCUS_BLOCKS) nb = FOCUS_BLOCKS;
-    hipLaunchKernelGGL(focus_partial_kernel, dim3((unsigned)nb), dim3(256), 0, cg_s(stream), mask, H, W, k, total, center,
-                       eps, (double*)ws);
+    hipLaunchKernelGGL(focus_partial_kernel, dim3((unsigned)nb, nmember), dim3(256), 0, cg_s(stream), mask, H, W, k, total,
+                       center, eps, (double*)ws);
     CG_LAUNCH_CHECK("focus_partial_kernel");
-    hipLaunchKernelGGL(focus_final_kernel, dim3(1), dim3(64), 0, cg_s(stream), (const double*)ws, (int)nb, sums);
+    hipLaunchKernelGGL(focus_final_kernel, dim3(nmember), dim3(64), 0, cg_s(stream), (const double*)ws, (int)nb, sums);
     CG_LAUNCH_CHECK("focus_final_kernel");
     return CG_OK;
 }
-extern "C" int cg_focus_total(const float* sums, size_t numel, float w_zo, float w_total, float w_tv, int use_abs,
-                              int use_square, float* out, cg_stream_t stream) {
-    CG_CHECK_ARG(sums && out && numel > 0, "cg_focus_total: bad args");
-    hipLaunchKernelGGL(focus_total_kernel, dim3(1), dim3(64), 0, cg_s(stream), sums, (float)numel, w_zo, w_total, w_tv,
-                       use_abs, use_square, out);
+extern "C" int cg_focus_total_g(const float* sums, size_t numel_per_member, int nmember, float w_zo, float w_total,
+                                float w_tv, int use_abs, int use_square, float* out, cg_stream_t stream) {
+    CG_CHECK_ARG(sums && out && numel_per_member > 0 && nmember > 0, "cg_focus_total: bad args");
+    hipLaunchKernelGGL(focus_total_kernel, dim3(nmember), dim3(64), 0, cg_s(stream), sums, (float)numel_per_member, w_zo,
+                       w_total, w_tv, use_abs, use_square, out);
     CG_LAUNCH_CHECK("focus_total_kernel");
     return CG_OK;
+}
+extern "C" int cg_focus_bwd_g(const float* mask, const float* sums, const float* gscale, int N, int H, int W, int k,
+                              int nmember, float center, float eps, float w_zo, float w_total, float w_tv, int use_abs,
+                              int use_square, float* d_mask, cg_stream_t stream) {
+    CG_CHECK_ARG(mask && sums && gscale && d_mask && N > 0 && H > 0 && W > 0 && k > 0 && nmember > 0 && N % nmember == 0,
+                 "cg_focus_bwd: bad args");
+    const int Nm = N / nmember;
+    hipLaunchKernelGGL(focus_bwd_kernel, dim3(ew_grid((size_t)Nm * H * W * k), nmember), dim3(256), 0, cg_s(stream), mask, sums,
+                       gscale, Nm, H, W, k, center, eps, w_zo, w_total, w_tv, use_abs, use_square, d_mask);
+    CG_LAUNCH_CHECK("focus_bwd_kernel");
+    return CG_OK;
+}
+extern "C" int cg_focus_sums(const float* mask, int N, int H, int W, int k, float center, float eps, float* sums,
+                             void* ws, size_t ws_bytes, cg_stream_t stream) {
+    return cg_focus_sums_g(mask, N, H, W, k, 1, center, eps, sums, ws, ws_bytes, stream);
+}
+extern "C" int cg_focus_total(const float* sums, size_t numel, float w_zo, float w_total, float w_tv, int use_abs,
+                              int use_square, float* out, cg_stream_t stream) {
+    return cg_focus_total_g(sums, numel, 1, w_zo, w_total, w_tv, use_abs, use_square, out, stream);
 }
 extern "C" int cg_focus_bwd(const float* mask, const float* sums, const float* gscale, int N, int H, int W, int k,
                             float center, float eps, float w_zo, float w_total, float w_tv, int use_abs,
                             int use_square, float* d_mask, cg_stream_t stream) {
-    CG_CHECK_ARG(mask && sums && gscale && d_mask && N > 0 && H > 0 && W > 0 && k > 0, "cg_focus_bwd: bad args");
-    EW_LAUNCH(focus_bwd_kernel, (size_t)N * H * W * k, mask, sums, gscale, N, H, W, k, center, eps, w_zo, w_total, w_tv,
-              use_abs, use_square, d_mask);
+    return cg_focus_bwd_g(mask, sums, gscale, N, H, W, k, 1, center, eps, w_zo, w_total, w_tv, use_abs, use_square, d_mask, stream);
 }
 
 extern "C" int cg_l1_mean_fwd(const float* a, const float* b, size_t n, float* loss, cg_stream_t stream) {
@@ -549,15 +629,24 @@ extern "C" int cg_l1_mean_bwd(const float* a, const float* b, const float* gscal
     EW_LAUNCH(l1_mean_bwd_kernel, n, a, b, gscale, n, da);
 }
 
-extern "C" int cg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
-                            float beta2, float eps, float weight_decay, int step, cg_stream_t stream) {
-    CG_CHECK_ARG(p && g && m && v && step >= 1, "cg_adam_step: bad args");
+// grouped: the same run [p, p+n) of `nmember` members whose pool slices sit `mstride` elements apart (one launch)
+extern "C" int cg_adam_step_g(float* p, const float* g, float* m, float* v, size_t n, int nmember, long long mstride,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                              cg_stream_t stream) {
+    CG_CHECK_ARG(p && g && m && v && step >= 1 && nmember >= 1 && (nmember == 1 || mstride > 0), "cg_adam_step: bad args");
     if (n == 0) return CG_OK;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    EW_LAUNCH(adam_kernel, n, p, g, m, v, n, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n), nmember), dim3(256), 0, cg_s(stream), p, g, m, v, n, beta1, beta2, eps,
+                       weight_decay, step_size, bc2_sqrt, mstride);
+    CG_LAUNCH_CHECK("adam_kernel");
+    return CG_OK;
+}
+extern "C" int cg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, cg_stream_t stream) {
+    return cg_adam_step_g(p, g, m, v, n, 1, 0, lr, beta1, beta2, eps, weight_decay, step, stream);
 }
 
 extern "C" int cg_gather_rows(const float* src, const int32_t* idx_dev, float* out, int nidx, size_t row_elems,
@@ -565,19 +654,41 @@ extern "C" int cg_gather_rows(const float* src, const int32_t* idx_dev, float* o
     CG_CHECK_ARG(src && idx_dev && out && nidx > 0 && row_elems > 0, "cg_gather_rows: bad args");
     EW_LAUNCH(gather_rows_kernel, (size_t)nidx * row_elems, src, idx_dev, out, nidx, row_elems);
 }
+extern "C" int cg_gather_rows2(const float* src_a, const float* src_b, const int32_t* idx_dev, float* out, int nidx,
+                               size_t row_elems, cg_stream_t stream) {
+    CG_CHECK_ARG(src_a && idx_dev && out && nidx > 0 && row_elems > 0 && row_elems % 4 == 0, "cg_gather_rows2: bad args");
+    EW_LAUNCH(gather_rows2_kernel, (size_t)nidx * (row_elems / 4), src_a, src_b ? src_b : src_a, idx_dev, out, nidx, row_elems / 4);
+}
+extern "C" int cg_gen_total(const float* focus, const float* adv, const float* lc, const float* w_match, float gan_w,
+                            float council_w, float* total, float* council, float* gcouncil, int nmember,
+                            cg_stream_t stream) {
+    CG_CHECK_ARG(total && nmember > 0, "cg_gen_total: bad args");
+    hipLaunchKernelGGL(gen_total_kernel, dim3(cg_div_up(nmember, 64)), dim3(64), 0, cg_s(stream), focus, adv, lc, w_match, gan_w,
+                       council_w, total, council, gcouncil, nmember);
+    CG_LAUNCH_CHECK("gen_total_kernel");
+    return CG_OK;
+}
 
-extern "C" int cg_ring_push(float* ring, int n, int pos, const float* value, cg_stream_t stream) {
-    CG_CHECK_ARG(ring && value && n > 0 && pos >= 0, "cg_ring_push: bad args");
-    hipLaunchKernelGGL(ring_kernel, dim3(1), dim3(64), 0, cg_s(stream), ring, (float*)nullptr, n, pos, value,
+// grouped rings: [nmember][n], one value / weight per member
+extern "C" int cg_ring_push_g(float* ring, int n, int pos, const float* value, int nmember, cg_stream_t stream) {
+    CG_CHECK_ARG(ring && value && n > 0 && pos >= 0 && nmember > 0, "cg_ring_push: bad args");
+    hipLaunchKernelGGL(ring_kernel, dim3(nmember), dim3(64), 0, cg_s(stream), ring, (float*)nullptr, n, pos, value,
                        (float*)nullptr, 0);
     CG_LAUNCH_CHECK("ring_kernel");
     return CG_OK;
 }
-extern "C" int cg_loss_match(float* ring_gan, float* ring_council, int n, int pos, const float* council_loss,
-                             float* w_out, cg_stream_t stream) {
-    CG_CHECK_ARG(ring_gan && ring_council && council_loss && w_out && n > 0 && pos >= 0, "cg_loss_match: bad args");
-    hipLaunchKernelGGL(ring_kernel, dim3(1), dim3(64), 0, cg_s(stream), ring_gan, ring_council, n, pos, council_loss,
+extern "C" int cg_loss_match_g(float* ring_gan, float* ring_council, int n, int pos, const float* council_loss,
+                               float* w_out, int nmember, cg_stream_t stream) {
+    CG_CHECK_ARG(ring_gan && ring_council && council_loss && w_out && n > 0 && pos >= 0 && nmember > 0, "cg_loss_match: bad args");
+    hipLaunchKernelGGL(ring_kernel, dim3(nmember), dim3(64), 0, cg_s(stream), ring_gan, ring_council, n, pos, council_loss,
                        w_out, 1);
     CG_LAUNCH_CHECK("ring_kernel");
     return CG_OK;
+}
+extern "C" int cg_ring_push(float* ring, int n, int pos, const float* value, cg_stream_t stream) {
+    return cg_ring_push_g(ring, n, pos, value, 1, stream);
+}
+extern "C" int cg_loss_match(float* ring_gan, float* ring_council, int n, int pos, const float* council_loss,
+                             float* w_out, cg_stream_t stream) {
+    return cg_loss_match_g(ring_gan, ring_council, n, pos, council_loss, w_out, 1, stream);
 }

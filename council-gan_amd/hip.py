@@ -26,6 +26,11 @@ class ConvGeom(ctypes.Structure):
                 ("dy", c_int8 * MAX_TAPS), ("dx", c_int8 * MAX_TAPS)]
 
 
+class Group(ctypes.Structure):
+    """cg_group: n council members whose parameters sit `stride` fp32 elements apart in one pool (optim.ParamPool)."""
+    _fields_ = [("n", c_int32), ("reserved", c_int32), ("stride", c_int64)]
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -42,7 +47,33 @@ _SIGS = {
     "cg_split_f16": (c_int, [_P, _P, c_size_t, c_size_t, c_float, _P]),
     "cg_conv2d_fwd_x3": (c_int, [POINTER(ConvGeom), _P, c_size_t, _P, c_size_t, c_float, _P, _P, _P, _P, c_size_t, _P, c_size_t,
                                  POINTER(c_int), c_int, _P, POINTER(c_int), _P]),
-    "cg_conv2d_fwd_x3_group": (c_int, [c_int, POINTER(ConvGeom), _P, c_size_t, _P, c_size_t, c_float, _P, _P, _P, c_int, _P]),
+    "cg_conv2d_fwd_x3_g": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, c_size_t, c_float, _P, _P, _P, _P, _P,
+                                   c_size_t, _P, c_size_t, POINTER(c_int), c_int, _P, POINTER(c_int), _P]),
+    "cg_conv2d_fwd_g": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, _P, _P, _P, _P, _P, c_size_t, POINTER(c_int), _P,
+                                POINTER(c_int), _P]),
+    "cg_split_f16_dynamic_capped": (c_int, [_P, _P, c_size_t, c_size_t, _P, c_int, c_float, _P]),
+    "cg_conv2d_dgrad_x3_wt_elems": (c_size_t, [POINTER(ConvGeom), c_int]),
+    "cg_conv2d_dgrad_x3_prep": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
+    "cg_conv2d_dgrad_x3_run": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_float, _P, c_int, c_int, _P, _P]),
+    "cg_conv2d_wgrad_x3_ok_g": (c_int, [POINTER(ConvGeom), POINTER(Group)]),
+    "cg_conv2d_wgrad_x3_g": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_size_t, _P, _P, _P, c_int, _P,
+                                     c_size_t, _P]),
+    "cg_conv2d_wgrad_workspace_g": (c_size_t, [POINTER(ConvGeom), POINTER(Group)]),
+    "cg_conv2d_wgrad_g": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "cg_conv2d_dgrad_workspace_g": (c_size_t, [POINTER(ConvGeom), POINTER(Group), c_int]),
+    "cg_conv2d_dgrad_g": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
+    "cg_lsgan_fwd_g": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "cg_lsgan_bwd_g": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "cg_focus_sums_g": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, c_size_t, _P]),
+    "cg_focus_total_g": (c_int, [_P, c_size_t, c_int, c_float, c_float, c_float, c_int, c_int, _P, _P]),
+    "cg_focus_bwd_g": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
+                               c_int, c_int, _P, _P]),
+    "cg_adam_step_g": (c_int, [_P, _P, _P, _P, c_size_t, c_int, ctypes.c_longlong, c_float, c_float, c_float, c_float, c_float,
+                               c_int, _P]),
+    "cg_ring_push_g": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
+    "cg_loss_match_g": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, _P]),
+    "cg_gather_rows2": (c_int, [_P, _P, _P, _P, c_int, c_size_t, _P]),
+    "cg_gen_total": (c_int, [_P, _P, _P, _P, c_float, c_float, _P, _P, _P, c_int, _P]),
     "cg_conv2d_fwd_amax": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, POINTER(c_int), _P]),
     "cg_conv2d_wgrad_x3_ok": (c_int, [POINTER(ConvGeom)]),
     "cg_conv2d_wgrad_x3": (c_int, [POINTER(ConvGeom), _P, c_size_t, _P, _P, c_size_t, _P, _P, _P, c_int, _P, c_size_t, _P]),

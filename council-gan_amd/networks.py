@@ -142,7 +142,7 @@ def conv_block_split(block, xs, upsample=False, residual=None, want_f32=False):
     k = block.kernel_size
     stats = []
     y = ops.conv2d_x3(xs, block._cg_wsplit, block.conv.out_channels, k, k, block.conv.bias, block.stride, block.padding,
-                       'none', upsample=upsample, stats=stats)
+                       'none', upsample=upsample, stats=stats, grp=ops._grp(block.conv.weight))
     if block.norm_type == 'adain':
         n = block.norm
         assert n.params is not None, "Please assign weight and bias before calling AdaIN!"
@@ -471,19 +471,24 @@ class MsImageDis(nn.Module):
         return outputs
 
     def calc_dis_loss(self, input_fake, input_real, weight=1.0):
-        """networks.py:56-82.  Fake and real run as ONE batch (the net has no cross-sample op)."""
-        b = input_fake.shape[0]
-        outs = self.forward(torch.cat((input_fake, input_real), 0))
-        tgt, wt = self._vec.get([0.0] * b + [1.0] * input_real.shape[0], [weight] * (b + input_real.shape[0]),
-                                input_fake.device)
+        """networks.py:56-82.  Fake and real run as ONE batch (the net has no cross-sample op).  Under ops.members(n)
+        `input_fake` holds the n members' fakes (member-major), `input_real` the one real batch they all see; the
+        discriminator batch is [fake_0 | real | fake_1 | real | ...] and the result one loss per member."""
+        n = ops.group_n()
+        b, br = input_fake.shape[0] // n, input_real.shape[0]
+        idx = []
+        for m in range(n):
+            idx += list(range(m * b, (m + 1) * b)) + [-r - 1 for r in range(br)]
+        outs = self.forward(ops.take_rows(input_fake, input_real, idx))
+        tgt, wt = self._vec.get(([0.0] * b + [1.0] * br) * n, [weight] * (n * (b + br)), input_fake.device)
         return ops.lsgan_loss(outs, tgt, wt, b)
 
     def calc_gen_loss(self, input_fake, input_real=None, weight=1.0):
-        """networks.py:84-110."""
-        b = input_fake.shape[0]
+        """networks.py:84-110 (one loss per member under ops.members(n))."""
+        nb = input_fake.shape[0]
         outs = self.forward(input_fake)
-        tgt, wt = self._vec.get([1.0] * b, [weight] * b, input_fake.device)
-        return ops.lsgan_loss(outs, tgt, wt, b)
+        tgt, wt = self._vec.get([1.0] * nb, [weight] * nb, input_fake.device)
+        return ops.lsgan_loss(outs, tgt, wt, nb // ops.group_n())
 
 
 class MsImageDisCouncil(nn.Module):
@@ -544,21 +549,43 @@ class MsImageDisCouncil(nn.Module):
         the reference re-runs the identical fake pass for every colleague pick (trainer_council.py:
         862-874); here fake and the distinct colleagues' images run once, as one batch."""
         b = input_fake.shape[0]
-        groups = 1 + len(reals)
-        x = torch.cat([input_fake] + list(reals), 0)
-        x_in = torch.cat([input] * groups, 0) if groups > 1 else input
+        pool = torch.cat(list(reals), 0) if len(reals) > 1 else (reals[0] if reals else None)     # API convenience only:
+        picks = [[(k, rw) for k, rw in enumerate(real_weights)]]         # the trainer calls calc_dis_loss_members directly
+        return self.calc_dis_loss_members(input_fake, pool, picks, input, fake_weight, weight)
+
+    def calc_dis_loss_members(self, x_full, x_cmp, picks, input, fake_weight, weight=1.0):
+        """The council-discriminator objective of n members as one batch (n = ops.group_n() = len(picks)).
+        x_full: the members' own translations, member-major [n*B]; x_cmp: comparison images, block j = rows [j*B, (j+1)*B);
+        picks[m]: [(block j, multiplicity), ...] -- the DISTINCT colleagues member m drew (trainer_council.py:861-868)
+        with how often; input: the one conditioning batch [B].  Discriminator batch of member m:
+        [own | cmp_j1 | cmp_j2 | ...] with per-sample loss weights; every member has the same number of blocks."""
+        n = ops.group_n()
+        if len(picks) != n:
+            raise ValueError("one pick list per member of the launch")
+        b = x_full.shape[0] // n
+        u = len(picks[0])
+        if any(len(p) != u for p in picks):
+            raise ValueError("members of one launch must compare against the same number of distinct colleagues")
+        idx, idx_in, tgt, wt = [], [], [], []
+        for m in range(n):
+            idx += list(range(m * b, (m + 1) * b))
+            tgt += [0.0] * b
+            wt += [weight * fake_weight] * b
+            for j, mult in picks[m]:
+                idx += [-(j * b + r) - 1 for r in range(b)]
+                tgt += [1.0] * b
+                wt += [weight * mult] * b
+            idx_in += list(range(b)) * (1 + u)
+        x = ops.take_rows(x_full, x_cmp, idx)
+        x_in = ops.take_rows(input, None, idx_in)
         outs = self.forward(x, x_in)
-        tgt = [0.0] * b
-        wt = [weight * fake_weight] * b
-        for r, rw in zip(reals, real_weights):
-            tgt += [1.0] * r.shape[0]
-            wt += [weight * rw] * r.shape[0]
-        tgt, wt = self._vec.get(tgt, wt, input_fake.device)
+        tgt, wt = self._vec.get(tgt, wt, x_full.device)
         return ops.lsgan_loss(outs, tgt, wt, b)
 
     def calc_gen_loss(self, input_fake, input, input_real=None, weight=1.0):
-        """networks.py:188-215."""
-        b = input_fake.shape[0]
+        """networks.py:188-215 (one loss per member under ops.members(n); `input` is then the member-major repetition
+        of the conditioning batch)."""
+        nb = input_fake.shape[0]
         outs = self.forward(input_fake, input)
-        tgt, wt = self._vec.get([1.0] * b, [weight] * b, input_fake.device)
-        return ops.lsgan_loss(outs, tgt, wt, b)
+        tgt, wt = self._vec.get([1.0] * nb, [weight] * nb, input_fake.device)
+        return ops.lsgan_loss(outs, tgt, wt, nb // ops.group_n())

@@ -10,6 +10,7 @@ Parameter gradients: when a parameter carries a `_cg_grad` buffer (a view into t
 optimizer's flat gradient buffer, see optim.py) the backward kernels accumulate straight into it
 and autograd receives None for that input; otherwise the gradient is returned normally.
 """
+import contextlib
 import ctypes
 from ctypes import byref, c_void_p
 
@@ -35,6 +36,49 @@ def _lib():
 
 def _off(t, elems):
     return c_void_p(t.data_ptr() + 4 * elems)
+
+
+# ------------------------------------------------------------------------------------------
+# member-batched ("grouped") execution
+# ------------------------------------------------------------------------------------------
+# Inside `with members(n):` every operator treats the batch dimension of its activations as n consecutive blocks of
+# samples, one per council member (the members' SAME layer runs as one launch): convolutions / linears read member z's
+# parameters z * pool.stride elements after the lead member's (optim.ParamPool; hip.Group = cg_group), the loss
+# reductions return one value per member; every other operator is per sample and does not care.
+class _Scope:
+    n = 1
+
+
+_G = _Scope()
+_group_cache = {}
+
+
+@contextlib.contextmanager
+def members(n):
+    prev, _G.n = _G.n, int(n)
+    try:
+        yield
+    finally:
+        _G.n = prev
+
+
+def group_n():
+    return _G.n
+
+
+def _grp(weight):
+    """byref(cg_group) for a parameter under the current scope, or None for an ordinary single-member call."""
+    n = _G.n
+    if n <= 1:
+        return None
+    pool = getattr(weight, '_cg_pool', None)
+    if pool is None:
+        raise hip.HipError("member-batched launch on a parameter that does not live in an optim.ParamPool")
+    key = (n, pool.stride)
+    g = _group_cache.get(key)
+    if g is None:
+        g = _group_cache[key] = hip.Group(n, 0, pool.stride)
+    return byref(g)
 
 
 # ------------------------------------------------------------------------------------------
@@ -98,15 +142,15 @@ def dgrad_classes(Hl, Wl, KH, KW, stride, pad):
     return out
 
 
-def conv_dgrad(g, dz, w, ci0, nci):
+def conv_dgrad(g, dz, w, ci0, nci, grp=None):
     """dx (w.r.t. channels [ci0, ci0+nci) of the conv input) from dz [N,Cout,Ho,Wo].  `g` is the FORWARD geometry of
     the layer; the library derives the output-parity classes of a strided conv (`dgrad_classes` above is the host
     restatement the CPU tests check) and runs them as one launch of the forward implicit-GEMM kernel on dz."""
     lib = _lib()
     N, H, W, up = g.N, g.H, g.W, g.up
     dxl = empty_nhwc(N, nci, H << up, W << up, dz)
-    ws = workspace(lib.cg_conv2d_dgrad_workspace(byref(g), nci))
-    check(lib.cg_conv2d_dgrad(byref(g), ptr(dz), ptr(w), ci0, nci, ptr(dxl), ptr(ws), ws.numel(), stream()),
+    ws = workspace(lib.cg_conv2d_dgrad_workspace_g(byref(g), grp, nci))
+    check(lib.cg_conv2d_dgrad_g(byref(g), grp, ptr(dz), ptr(w), ci0, nci, ptr(dxl), ptr(ws), ws.numel(), stream()),
           "cg_conv2d_dgrad")
     if not up:
         return dxl
@@ -116,11 +160,15 @@ def conv_dgrad(g, dz, w, ci0, nci):
 
 
 class _Conv2d(torch.autograd.Function):
-    """act(conv2d(zero_pad(x (++ x2)), weight) + bias); networks.py:515-521 without the norm."""
+    """act(conv2d(zero_pad(x (++ x2)), weight) + bias); networks.py:515-521 without the norm.  Under ops.members(n) the
+    batch holds n members' samples and `weight` / `bias` / the gradient buffers are the LEAD member's (the others sit
+    pool.stride elements further on)."""
 
     @staticmethod
     def forward(ctx, x, x2, weight, bias, wgrad_buf, bgrad_buf, stride, pad, act, up, stats, xsplit=None, wsplit=None,
-                out_split=None, amax_out=None):
+                out_split=None, amax_out=None, wmgr=None, wref=None):
+        # wref = (cg_group or None, the Parameter object): resolved by the caller, where the tensor still carries its
+        # Python attributes
         lib = _lib()
         x, x2, w = nhwc(x), nhwc(x2), nhwc(weight)
         N, C1, H, W = x.shape
@@ -130,52 +178,45 @@ class _Conv2d(torch.autograd.Function):
             raise ValueError("conv weight expects %d input channels, got %d" % (Ct, C1 + C2))
         if x2 is not None and tuple(x2.shape[0:1] + x2.shape[2:]) != (N, H, W):
             raise ValueError("concat sources must agree in N, H, W")
+        grp, wparam = wref if wref is not None else (None, None)
+        if grp is not None and w.data_ptr() != weight.data_ptr():
+            raise hip.HipError("member-batched launch: the weight is not stored channels_last in its pool")
         g = fwd_geom(N, H, W, C1, C2, int(up), KH, KW, stride, pad, Cout, act)
         y = empty_nhwc(N, Cout, g.Ho, g.Wo, x)
+        want_stats = stats is not None and act == 0
+        rows = ctypes.c_int(0)
+        sws, sbytes, rp = None, 0, None
+        if want_stats:           # an instance norm follows: the conv epilogue emits its partial sums when it can
+            sws = workspace(((N * g.Ho * g.Wo + 63) // 64) * Cout * 16, slot=1)
+            sbytes, rp = sws.numel(), byref(rows)
+        state, nslots = None, None
         if xsplit is not None and wsplit is not None and x3_eligible(C1, C2):
-            # split-precision forward (fp16 x 3 MFMA, 22 significand bits); the backward below is unchanged and reads
-            # the fp32 operands saved on the tape
-            rows = ctypes.c_int(0)
-            sws, sbytes, rp = None, 0, None
-            if stats is not None and act == 0:
-                sws = workspace(((N * g.Ho * g.Wo + 63) // 64) * Cout * 16, slot=1)
-                sbytes, rp = sws.numel(), byref(rows)
+            # split-precision forward (fp16 x 3 MFMA, 22 significand bits)
             ysp = None
             if out_split is not None:
                 ysp = SplitTensor(torch.empty(2 * y.numel(), dtype=torch.float16, device=y.device), y.shape)
                 out_split.append(ysp)
-            state, nslots = None, None
             if amax_out is not None and ysp is None:     # the consumer will split y dynamically: hand it the block maxima
                 state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=y.device), ctypes.c_int(0)
-            check(lib.cg_conv2d_fwd_x3(byref(g), xsplit.hi_ptr(), xsplit.lo, wsplit.hi_ptr(), wsplit.lo, float(wsplit.scale),
-                                       xsplit.scale_ptr(), ptr(bias), ptr(y), ysp.hi_ptr() if ysp else None,
-                                       ysp.lo if ysp else 0, ptr(sws), sbytes, rp, -1, ptr(state),
-                                       byref(nslots) if nslots is not None else None, stream()), "cg_conv2d_fwd_x3")
-            if nslots is not None and nslots.value:
-                amax_out.append((state, nslots.value))
-            if stats is not None and rows.value:
-                stats.append((sws, rows.value))
-        elif stats is not None and act == 0:
-            # an instance norm follows: let the conv epilogue emit its partial sums (ops.instance_norm consumes them)
-            m = N * g.Ho * g.Wo
-            sws = workspace(((m + 63) // 64) * Cout * 16, slot=1)
-            rows = ctypes.c_int(0)
-            check(lib.cg_conv2d_fwd_stats(byref(g), ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), ptr(sws), sws.numel(),
-                                          byref(rows), stream()), "cg_conv2d_fwd_stats")
-            if rows.value:
-                stats.append((sws, rows.value))
-        elif amax_out is not None:
-            state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=y.device), ctypes.c_int(0)
-            check(lib.cg_conv2d_fwd_amax(byref(g), ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), ptr(state), byref(nslots),
-                                         stream()), "cg_conv2d_fwd_amax")
-            if nslots.value:
-                amax_out.append((state, nslots.value))
+            check(lib.cg_conv2d_fwd_x3_g(byref(g), grp, xsplit.hi_ptr(), xsplit.lo, wsplit.hi_ptr(), wsplit.lo,
+                                         float(wsplit.scale), wsplit.scale_ptr(), xsplit.scale_ptr(), ptr(bias), ptr(y),
+                                         ysp.hi_ptr() if ysp else None, ysp.lo if ysp else 0, ptr(sws), sbytes, rp, -1,
+                                         ptr(state), byref(nslots) if nslots is not None else None, stream()),
+                  "cg_conv2d_fwd_x3")
         else:
-            check(lib.cg_conv2d_fwd(byref(g), ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), stream()), "cg_conv2d_fwd")
+            if amax_out is not None and not want_stats:
+                state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=y.device), ctypes.c_int(0)
+            check(lib.cg_conv2d_fwd_g(byref(g), grp, ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), ptr(sws), sbytes, rp,
+                                      ptr(state), byref(nslots) if nslots is not None else None, stream()), "cg_conv2d_fwd")
+        if nslots is not None and nslots.value:
+            amax_out.append((state, nslots.value))
+        if want_stats and rows.value:
+            stats.append((sws, rows.value))
         ctx.save_for_backward(x, x2, w, y if act else None)
         ctx.xsplit = xsplit if (xsplit is not None and wsplit is not None) else None     # reused by the x3 weight gradient
         ctx.g, ctx.meta = g, (KH, KW, stride, pad, act, int(up), bias is not None)
         ctx.wgrad_buf, ctx.bgrad_buf = wgrad_buf, bgrad_buf
+        ctx.grp, ctx.weight, ctx.wmgr = grp, wparam, wmgr
         return y
 
     @staticmethod
@@ -183,7 +224,7 @@ class _Conv2d(torch.autograd.Function):
         lib = _lib()
         x, x2, w, y = ctx.saved_tensors
         KH, KW, stride, pad, act, up, has_bias = ctx.meta
-        g = ctx.g
+        g, grp = ctx.g, ctx.grp
         amax = getattr(dy, "_cg_amax", None)
         dy = nhwc(dy)
         dx = dw = db = None
@@ -191,7 +232,7 @@ class _Conv2d(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
         need_dw = ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3])
         x3_dgrad = X3_BACKWARD and need_dx and g.Cout % 32 == 0 and g.stride <= 2
-        x3_wgrad = X3_BACKWARD and need_dw and ctx.xsplit is not None and bool(lib.cg_conv2d_wgrad_x3_ok(byref(g)))
+        x3_wgrad = X3_BACKWARD and need_dw and ctx.xsplit is not None and bool(lib.cg_conv2d_wgrad_x3_ok_g(byref(g), grp))
         fp32_needed = (need_dx and not x3_dgrad) or (need_dw and not x3_wgrad)
         dzs = None
         if act:
@@ -205,33 +246,39 @@ class _Conv2d(torch.autograd.Function):
             if x3_dgrad or x3_wgrad:
                 dzs = split_f16_dynamic(dz, amax)
         if need_dw:
-            ws = workspace(lib.cg_conv2d_wgrad_workspace(byref(g)))
+            ws = workspace(lib.cg_conv2d_wgrad_workspace_g(byref(g), grp))
             if ctx.wgrad_buf is not None:
-                # accumulate straight into the optimizer's flat gradient buffer (optim.py)
+                # accumulate straight into the optimizer's flat gradient buffer (optim.py); grouped: every member's slice
                 dw_t, acc = ctx.wgrad_buf, 1
                 db_t = ctx.bgrad_buf if has_bias else None
                 dw_t._cg_touched = True
                 if db_t is not None:
                     db_t._cg_touched = True
             else:
+                if grp is not None:
+                    raise hip.HipError("member-batched weight gradients need pool-backed gradient buffers")
                 dw_t, acc = torch.empty_like(w), 0
                 db_t = torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if has_bias else None
                 dw, db = dw_t, db_t
             if x3_wgrad:
                 xs = ctx.xsplit
-                check(lib.cg_conv2d_wgrad_x3(byref(g), xs.hi_ptr(), xs.lo, xs.scale_ptr(), dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(),
-                                             ptr(dw_t), ptr(db_t), acc, ptr(ws), ws.numel(), stream()), "cg_conv2d_wgrad_x3")
+                check(lib.cg_conv2d_wgrad_x3_g(byref(g), grp, xs.hi_ptr(), xs.lo, xs.scale_ptr(), dzs.hi_ptr(), dzs.lo,
+                                               dzs.scale_ptr(), ptr(dw_t), ptr(db_t), acc, ptr(ws), ws.numel(), stream()),
+                      "cg_conv2d_wgrad_x3")
             else:
-                check(lib.cg_conv2d_wgrad(byref(g), ptr(x), ptr(x2), ptr(dz), ptr(dw_t), ptr(db_t), acc, ptr(ws),
-                                          ws.numel(), stream()), "cg_conv2d_wgrad")
+                check(lib.cg_conv2d_wgrad_g(byref(g), grp, ptr(x), ptr(x2), ptr(dz), ptr(dw_t), ptr(db_t), acc, ptr(ws),
+                                            ws.numel(), stream()), "cg_conv2d_wgrad")
         # data gradients: split-precision kernel when the layer qualifies (dz gets a device-side power-of-two scale)
-        dgrad, dz_in = (conv_dgrad_x3, dzs) if x3_dgrad else (conv_dgrad, dz)
+        def dgrad(ci0, nci):
+            if x3_dgrad:
+                return conv_dgrad_x3(g, dzs, w, ci0, nci, grp=grp, weight=ctx.weight, wmgr=ctx.wmgr)
+            return conv_dgrad(g, dz, w, ci0, nci, grp=grp)
         if ctx.needs_input_grad[0]:
-            dx = dgrad(g, dz_in, w, 0, x.shape[1])
+            dx = dgrad(0, x.shape[1])
         dx2 = None
         if x2 is not None and ctx.needs_input_grad[1]:
-            dx2 = dgrad(g, dz_in, w, x.shape[1], x2.shape[1])
-        return dx, dx2, dw, db, None, None, None, None, None, None, None, None, None, None, None
+            dx2 = dgrad(x.shape[1], x2.shape[1])
+        return (dx, dx2, dw, db) + (None,) * 13
 
 
 X3_FORWARD = True     # module switches (Council_Trainer sets them from the config): split-precision forward convolutions,
@@ -269,7 +316,8 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=
                       weight.shape[0] % 32 == 0) else None
     y = _Conv2d.apply(x, x2, weight, bias, getattr(weight, "_cg_grad", None),
                       getattr(bias, "_cg_grad", None) if bias is not None else None,
-                      int(stride), int(pad), ACT[act], bool(upsample), stats, xsplit, wsplit, out_split, amax_out)
+                      int(stride), int(pad), ACT[act], bool(upsample), stats, xsplit, wsplit, out_split, amax_out, wmgr,
+                      (_grp(weight), weight))
     if out_split:
         y._cg_split = out_split[0]
     if amax_out:
@@ -283,7 +331,7 @@ def linear(x, weight, bias=None, act="none"):
     w4 = weight.view(weight.shape[0], weight.shape[1], 1, 1)
     y = _Conv2d.apply(x.reshape(n, -1, 1, 1), None, w4, bias, getattr(weight, "_cg_grad", None),
                       getattr(bias, "_cg_grad", None) if bias is not None else None, 1, 0, ACT[act], False, None, None, None,
-                      None)
+                      None, None, None, (_grp(weight), weight))
     return y.reshape(n, -1)
 
 
@@ -504,34 +552,77 @@ class SplitTensor:
 
 
 class SplitWeights:
-    """{hi, lo} fp16 planes of ALL parameters of one flat optimizer (optim.FlatAdam), pre-scaled by hip.X3_WSCALE and
-    re-split lazily -- one kernel over the flat buffer -- whenever the optimizer's `version` moved (a step, a
-    checkpoint load).  `get(weight)` returns the SplitTensor view of one conv weight, or None for tensors the
-    optimizer does not own."""
+    """{hi, lo} fp16 planes of ALL parameters of one optimizer (optim.FlatAdam) or of one pool of member optimizers
+    (optim.ParamPool), re-split lazily -- one kernel over the flat storage -- whenever the owner's `version` moved (a step,
+    a checkpoint load).  The power-of-two scale is chosen ON THE DEVICE from the storage's largest magnitude, capped at
+    hip.X3_WSCALE = 2^10: ordinary weights (|w| <= 1/16) get exactly the static scale of round 1, larger ones (a loaded
+    checkpoint) the smaller scale that keeps their hi halves finite; consumers read it from `state` (scale_ptr).
+    `get(weight)` returns the SplitTensor view of one conv weight, or None for tensors the owner does not hold.
+    `dgrad_weights(...)` caches the re-laid-out, split data-gradient weights of a layer per weight version."""
 
-    def __init__(self, opt):
-        self.opt = opt
+    def __init__(self, owner):
+        self.owner = owner
         self.version = None
         self.buf = None
+        self.state = None
         self.views = {}
+        self._dgrad = {}
+
+    def _storage(self):
+        o = self.owner
+        if hasattr(o, 'opts'):                       # ParamPool
+            if o.data is None:
+                return None
+            return o.data, [(p, k * o.stride + off) for k, opt in enumerate(o.opts)
+                            for p, off in zip(opt._params, opt.flat['offs'])]
+        if o._flat is None:
+            return None
+        return o.flat['data'], list(zip(o._params, o.flat['offs']))
+
+    def refresh(self):
+        st = self._storage()
+        if st is None:
+            return False
+        if self.version != self.owner.version:
+            data, table = st
+            total = data.numel()
+            if self.buf is None or self.buf.numel() != 2 * total or self.buf.device != data.device:
+                self.buf = torch.empty(2 * total, dtype=torch.float16, device=data.device)
+                self.state = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=data.device)
+            check(_lib().cg_split_f16_dynamic_capped(ptr(data), ptr(self.buf), total, x3_lo(total), ptr(self.state), 0,
+                                                     hip.X3_WSCALE, stream()), "cg_split_f16_dynamic_capped")
+            self.views = {}
+            for p, o in table:
+                if p.dim() == 4:
+                    self.views[id(p)] = SplitTensor(self.buf, (p.shape[0], p.shape[2], p.shape[3], p.shape[1]), off=o,
+                                                    lo=x3_lo(total), scale=1.0, state=self.state)
+            self.version = self.owner.version
+            self._dgrad = {}
+        return True
 
     def get(self, weight):
-        opt = self.opt
-        if opt._flat is None:
+        if not self.refresh():
             return None
-        if self.version != opt.version:
-            f = opt.flat
-            total = f['data'].numel()
-            if self.buf is None or self.buf.numel() != 2 * total or self.buf.device != f['data'].device:
-                self.buf = torch.empty(2 * total, dtype=torch.float16, device=f['data'].device)
-            check(_lib().cg_split_f16(ptr(f['data']), ptr(self.buf), total, x3_lo(total), hip.X3_WSCALE, stream()), "cg_split_f16")
-            self.views = {}
-            for p, o in zip(opt._params, f['offs']):
-                if p.dim() == 4:
-                    self.views[id(p)] = SplitTensor(self.buf, (p.shape[0], p.shape[2], p.shape[3], p.shape[1]), off=o, lo=x3_lo(total),
-                                                    scale=hip.X3_WSCALE)
-            self.version = opt.version
         return self.views.get(id(weight))
+
+    def dgrad_weights(self, weight, w, g, ci0, nci, grp, n):
+        """Prepared ({hi, lo}, per-class [ci][tc][co]) data-gradient weights of `weight` for the current version and
+        member scope: one cg_conv2d_dgrad_x3_prep launch per (layer, version) instead of one per backward launch."""
+        if not self.refresh() or id(weight) not in self.views:
+            return None
+        key = (id(weight), ci0, nci, n)
+        wt = self._dgrad.get(key)
+        if wt is None:
+            lib = _lib()
+            elems = lib.cg_conv2d_dgrad_x3_wt_elems(byref(g), nci)
+            wt = torch.empty(2 * n * elems, dtype=torch.float16, device=w.device)
+            check(lib.cg_conv2d_dgrad_x3_prep(byref(g), grp, ptr(w), ci0, nci, 1.0, self.scale_ptr(), ptr(wt),
+                                              wt.numel() * 2, stream()), "cg_conv2d_dgrad_x3_prep")
+            self._dgrad[key] = wt
+        return wt
+
+    def scale_ptr(self):
+        return c_void_p(self.state.data_ptr() + 4)
 
 
 def x3_eligible(C1, C2):
@@ -572,16 +663,24 @@ def act_bwd_split(dy, y, act, want_fp32):
     return dz, SplitTensor(buf, dy.shape, state=state)
 
 
-def conv_dgrad_x3(g, dz, w, ci0, nci):
-    """conv_dgrad on the split-precision kernel: dz is split with its device-side scale, the weights are re-laid-out
-    and split by the library; needs Cout % 32 == 0."""
+def conv_dgrad_x3(g, dz, w, ci0, nci, grp=None, weight=None, wmgr=None):
+    """conv_dgrad on the split-precision kernel: dz is split with its device-side scale; needs Cout % 32 == 0.  The weights
+    are re-laid-out and split per launch into the workspace -- or, for a parameter of a SplitWeights-managed optimizer
+    (`weight`, `wmgr`), once per weight version (SplitWeights.dgrad_weights)."""
     lib = _lib()
     N, H, W, up = g.N, g.H, g.W, g.up
     dzs = dz if isinstance(dz, SplitTensor) else split_f16_dynamic(dz)
     dxl = torch.empty((N, nci, H << up, W << up), dtype=torch.float32, device=dzs.buf.device, memory_format=CL)
-    ws = workspace(lib.cg_conv2d_dgrad_workspace(byref(g), nci))
-    check(lib.cg_conv2d_dgrad_x3(byref(g), dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), ptr(w), ci0, nci, ptr(dxl), ptr(ws), ws.numel(),
-                                 stream()), "cg_conv2d_dgrad_x3")
+    wt = wmgr.dgrad_weights(weight, w, g, ci0, nci, grp, _G.n) if (wmgr is not None and weight is not None) else None
+    if wt is not None:
+        check(lib.cg_conv2d_dgrad_x3_run(byref(g), grp, dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), ptr(wt), 1.0, wmgr.scale_ptr(),
+                                         ci0, nci, ptr(dxl), stream()), "cg_conv2d_dgrad_x3_run")
+    else:
+        if grp is not None:
+            raise hip.HipError("member-batched split-precision data gradient needs pool-managed weights")
+        ws = workspace(lib.cg_conv2d_dgrad_workspace(byref(g), nci))
+        check(lib.cg_conv2d_dgrad_x3(byref(g), dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), ptr(w), ci0, nci, ptr(dxl), ptr(ws),
+                                     ws.numel(), stream()), "cg_conv2d_dgrad_x3")
     if not up:
         return dxl
     dx = empty_nhwc(N, nci, H, W, dxl)
@@ -589,7 +688,7 @@ def conv_dgrad_x3(g, dz, w, ci0, nci):
     return dx
 
 
-def conv2d_x3(xs, wsplit, Cout, KH, KW, bias=None, stride=1, pad=0, act="none", upsample=False, stats=None):
+def conv2d_x3(xs, wsplit, Cout, KH, KW, bias=None, stride=1, pad=0, act="none", upsample=False, stats=None, grp=None):
     """act(conv2d(zero_pad(x), W) + bias) on the fp16 MFMA with every product expanded as ah*bh + ah*bl + al*bh.
     xs: SplitTensor activation; wsplit: SplitTensor over the physical [Cout][KH][KW][Cin] weight.  No autograd."""
     if torch.is_grad_enabled() and (bias is not None and bias.requires_grad):
@@ -606,8 +705,9 @@ def conv2d_x3(xs, wsplit, Cout, KH, KW, bias=None, stride=1, pad=0, act="none", 
         sbytes, rp = sws.numel(), byref(rows)
     if xs.scale != 1.0:
         raise hip.HipError("conv2d_x3: activations carry a static scale of 1 or a device-side one")
-    check(lib.cg_conv2d_fwd_x3(byref(g), xs.hi_ptr(), xs.lo, wsplit.hi_ptr(), wsplit.lo, float(wsplit.scale), xs.scale_ptr(),
-                               ptr(bias), ptr(y), None, 0, ptr(sws), sbytes, rp, -1, None, None, stream()), "cg_conv2d_fwd_x3")
+    check(lib.cg_conv2d_fwd_x3_g(byref(g), grp, xs.hi_ptr(), xs.lo, wsplit.hi_ptr(), wsplit.lo, float(wsplit.scale),
+                                 wsplit.scale_ptr(), xs.scale_ptr(), ptr(bias), ptr(y), None, 0, ptr(sws), sbytes, rp, -1, None,
+                                 None, stream()), "cg_conv2d_fwd_x3")
     if stats is not None and rows.value:
         stats.append((sws, rows.value))
     return y
@@ -753,21 +853,22 @@ def mask_blend(new_x, im_in, od, k):
 # ------------------------------------------------------------------------------------------
 class _Lsgan(torch.autograd.Function):
     """sum over scales of  sum_s wt[s] * mean_hw (o - tgt[s])^2 / group   (networks.py:64,90,166,194).
-    tgt / wt are device vectors with one entry per sample of the (batched) discriminator input."""
+    tgt / wt are device vectors with one entry per sample of the (batched) discriminator input.  Under ops.members(n)
+    the samples are n consecutive member blocks and the result is a vector of n per-member losses."""
 
     @staticmethod
-    def forward(ctx, tgt, wt, group, *outs):
+    def forward(ctx, tgt, wt, group, nm, *outs):
         lib = _lib()
-        loss = torch.empty(1, dtype=torch.float32, device=tgt.device)
+        loss = torch.empty(nm, dtype=torch.float32, device=tgt.device)
         outs = [o.contiguous() for o in outs]
         for i, o in enumerate(outs):
             nb = o.shape[0]
             hw = o.numel() // nb
-            check(lib.cg_lsgan_fwd(ptr(o), ptr(tgt), ptr(wt), nb, hw, group, ptr(loss), int(i > 0), stream()),
+            check(lib.cg_lsgan_fwd_g(ptr(o), ptr(tgt), ptr(wt), nb, hw, group, nm, ptr(loss), int(i > 0), stream()),
                   "cg_lsgan_fwd")
         ctx.save_for_backward(tgt, wt, *outs)
-        ctx.group = group
-        return loss.view(())
+        ctx.group, ctx.nm = group, nm
+        return loss if nm > 1 else loss.view(())
 
     @staticmethod
     def backward(ctx, g):
@@ -779,59 +880,62 @@ class _Lsgan(torch.autograd.Function):
             nb = o.shape[0]
             hw = o.numel() // nb
             d = torch.empty_like(o)
-            check(lib.cg_lsgan_bwd(ptr(o), ptr(tgt), ptr(wt), ptr(g), nb, hw, ctx.group, ptr(d), stream()),
+            check(lib.cg_lsgan_bwd_g(ptr(o), ptr(tgt), ptr(wt), ptr(g), nb, hw, ctx.group, ctx.nm, ptr(d), stream()),
                   "cg_lsgan_bwd")
             grads.append(d)
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
 def lsgan_loss(outs, tgt, wt, group):
-    return _Lsgan.apply(tgt, wt, int(group), *outs)
+    """`group` = samples per member that count as one batch mean (the reference's per-call batch size)."""
+    return _Lsgan.apply(tgt, wt, int(group), _G.n, *outs)
 
 
 class _FocusLoss(torch.autograd.Function):
     """w_zo * mask_zero_one + w_total * mask_small + w_tv * TV   (trainer_council.py:230-250).
-    Returns (total, parts[3]) -- parts = the three unweighted criteria, for logging."""
+    Returns (total, parts[3]) -- parts = the three unweighted criteria, for logging; under ops.members(n): total [n],
+    parts [n, 3], every member's criteria over its own block of masks."""
 
     @staticmethod
-    def forward(ctx, mask, center, eps, w_zo, w_total, w_tv, use_abs, use_square, reduce):
+    def forward(ctx, mask, center, eps, w_zo, w_total, w_tv, use_abs, use_square, reduce, nm):
         lib = _lib()
         mask = nhwc(mask)
         N, k, H, W = mask.shape
-        sums = torch.empty(3, dtype=torch.float32, device=mask.device)
-        out = torch.empty(4, dtype=torch.float32, device=mask.device)
-        ws = workspace(lib.cg_focus_workspace())
-        check(lib.cg_focus_sums(ptr(mask), N, H, W, k, center, eps, ptr(sums), ptr(ws), ws.numel(), stream()),
+        sums = torch.empty(3 * nm, dtype=torch.float32, device=mask.device)
+        out = torch.empty(4 * nm, dtype=torch.float32, device=mask.device)
+        ws = workspace(nm * lib.cg_focus_workspace())
+        check(lib.cg_focus_sums_g(ptr(mask), N, H, W, k, nm, center, eps, ptr(sums), ptr(ws), ws.numel(), stream()),
               "cg_focus_sums")
         if reduce is not None:
             # data parallelism inside a member: with the MEAN of the replicas' sums every rank evaluates the full-batch
             # criteria (the squared mask mean is not linear in the batch) and back-propagates world-size times its
             # share, which the gradient averaging turns into the full-batch gradient
             reduce(sums)
-        check(lib.cg_focus_total(ptr(sums), mask.numel(), w_zo, w_total, w_tv, int(use_abs), int(use_square), ptr(out),
-                                 stream()), "cg_focus_total")
+        check(lib.cg_focus_total_g(ptr(sums), mask.numel() // nm, nm, w_zo, w_total, w_tv, int(use_abs), int(use_square),
+                                   ptr(out), stream()), "cg_focus_total")
         ctx.save_for_backward(mask, sums)
-        ctx.meta = (center, eps, w_zo, w_total, w_tv, int(use_abs), int(use_square))
-        parts = out[1:]
+        ctx.meta = (center, eps, w_zo, w_total, w_tv, int(use_abs), int(use_square), nm)
+        out = out.view(nm, 4)
+        total, parts = (out[:, 0], out[:, 1:]) if nm > 1 else (out[0, 0], out[0, 1:])
         ctx.mark_non_differentiable(parts)
-        return out[0], parts
+        return total, parts
 
     @staticmethod
     def backward(ctx, g, _gparts):
         lib = _lib()
         mask, sums = ctx.saved_tensors
-        center, eps, w_zo, w_total, w_tv, use_abs, use_square = ctx.meta
+        center, eps, w_zo, w_total, w_tv, use_abs, use_square, nm = ctx.meta
         N, k, H, W = mask.shape
         g = g.contiguous()
         d = torch.empty_like(mask)
-        check(lib.cg_focus_bwd(ptr(mask), ptr(sums), ptr(g), N, H, W, k, center, eps, w_zo, w_total, w_tv, use_abs,
-                               use_square, ptr(d), stream()), "cg_focus_bwd")
-        return d, None, None, None, None, None, None, None, None
+        check(lib.cg_focus_bwd_g(ptr(mask), ptr(sums), ptr(g), N, H, W, k, nm, center, eps, w_zo, w_total, w_tv, use_abs,
+                                 use_square, ptr(d), stream()), "cg_focus_bwd")
+        return (d,) + (None,) * 9
 
 
 def focus_loss(mask, center, eps, w_zo, w_total, w_tv, use_abs, use_square, reduce=None):
     return _FocusLoss.apply(mask, float(center), float(eps), float(w_zo), float(w_total), float(w_tv),
-                            bool(use_abs), bool(use_square), reduce)
+                            bool(use_abs), bool(use_square), reduce, _G.n)
 
 
 class _L1Mean(torch.autograd.Function):
@@ -868,6 +972,55 @@ def l1_mean(a, b):
 def fill_(t, value):
     check(_lib().cg_fill(ptr(t), t.numel(), float(value), stream()), "cg_fill")
     return t
+
+
+_idx_cache = {}
+
+
+def _index_tensor(idx, device):
+    key = (tuple(idx), str(device))
+    t = _idx_cache.get(key)
+    if t is None:
+        if len(_idx_cache) > 512:
+            _idx_cache.clear()
+        t = _idx_cache[key] = torch.tensor(list(idx), dtype=torch.int32, device=device)
+    return t
+
+
+def take_rows(a, b, idx, out=None):
+    """out[i] = a[idx[i]] if idx[i] >= 0 else b[-idx[i] - 1] along the batch dimension (NHWC rows): how the discriminator
+    batches [own fake | real] / [own translation | colleagues' translations] of all members are assembled -- one copy
+    kernel instead of torch.cat.  `idx` is a host sequence (cached on the device by value)."""
+    a = nhwc(a) if a.dim() == 4 else a.contiguous()
+    if b is not None:
+        b = nhwc(b) if b.dim() == 4 else b.contiguous()
+    row = a[0].numel()
+    if row % 4:
+        raise ValueError("take_rows: rows must be a multiple of 4 floats")
+    if b is not None and b[0].numel() != row:
+        raise ValueError("take_rows: sources differ in row size")
+    if out is None:
+        shape = (len(idx),) + tuple(a.shape[1:])
+        out = torch.empty(shape, dtype=torch.float32, device=a.device, memory_format=CL) if a.dim() == 4 else \
+            torch.empty(shape, dtype=torch.float32, device=a.device)
+    elif out.shape[0] != len(idx) or out[0].numel() != row or not (out.is_contiguous(memory_format=CL) if out.dim() == 4
+                                                                    else out.is_contiguous()):
+        raise ValueError("take_rows: `out` must be a dense NHWC block of len(idx) rows")
+    check(_lib().cg_gather_rows2(ptr(a), ptr(b), ptr(_index_tensor(idx, a.device)), ptr(out), len(idx), row, stream()),
+          "cg_gather_rows2")
+    return out
+
+
+def gen_total(focus4, adv, lc, w_match, gan_w, council_w, n):
+    """Per-member generator objective and the pieces train.py logs (cg_gen_total): returns (total[n], council[n],
+    gcouncil[n]); any of focus4 ([n, 4] from focus_loss), adv, lc, w_match may be None."""
+    dev = next(t for t in (focus4, adv, lc) if t is not None).device
+    total = torch.empty(n, dtype=torch.float32, device=dev)
+    council = torch.empty(n, dtype=torch.float32, device=dev)
+    gcouncil = torch.empty(n, dtype=torch.float32, device=dev)
+    check(_lib().cg_gen_total(ptr(focus4), ptr(adv), ptr(lc), ptr(w_match), float(gan_w), float(council_w), ptr(total),
+                              ptr(council), ptr(gcouncil), n, stream()), "cg_gen_total")
+    return total, council, gcouncil
 
 
 def gather_rows(src, idx_dev, nidx):

@@ -40,11 +40,8 @@ class FlatAdam(torch.optim.Optimizer):
         self.version = 0          # bumped whenever the parameter values may have changed (step / load / move)
 
     # -- flat storage ---------------------------------------------------------------------
-    def materialize(self, device):
-        """Move every parameter into the flat buffer on `device` (idempotent per device)."""
-        device = torch.device(device)
-        if self._flat is not None and self._flat["data"].device == device:
-            return
+    def layout(self):
+        """(start offsets, padded total) of the parameters inside this optimizer's flat buffers."""
         sizes = [p.numel() for p in self._params]
         # every parameter starts on a 32-ELEMENT boundary of the flat buffers: the fp16 {hi, lo} mirror of the buffer
         # (ops.SplitWeights) interleaves the halves per 32 elements of the flat index, so a tensor's groups must not
@@ -53,14 +50,31 @@ class FlatAdam(torch.optim.Optimizer):
         for n in sizes:
             starts.append(total)
             total = (total + n + 31) & ~31
+        return sizes, starts, total
+
+    def materialize(self, device, storage=None):
+        """Move every parameter into the flat buffer on `device` (idempotent per device).  `storage`: (data, grad, m, v)
+        slices of a ParamPool that become this optimizer's buffers instead of private allocations."""
+        device = torch.device(device)
+        if self._flat is not None and self._flat["data"].device == device and storage is None:
+            return
+        sizes, starts, total = self.layout()
         old = self._flat
-        data = torch.zeros(total, dtype=torch.float32, device=device)
-        grad = torch.zeros(total, dtype=torch.float32, device=device)
-        m = torch.zeros(total, dtype=torch.float32, device=device)
-        v = torch.zeros(total, dtype=torch.float32, device=device)
-        if old is not None:
-            m.copy_(old["m"])
-            v.copy_(old["v"])
+        if storage is not None:
+            data, grad, m, v = storage
+            if min(t.numel() for t in storage) < total:
+                raise ValueError("pool slice smaller than the optimizer's parameters")
+            for t in storage:
+                t.zero_()
+        else:
+            data = torch.zeros(total, dtype=torch.float32, device=device)
+            grad = torch.zeros(total, dtype=torch.float32, device=device)
+            m = torch.zeros(total, dtype=torch.float32, device=device)
+            v = torch.zeros(total, dtype=torch.float32, device=device)
+        if old is not None:          # moments survive a move (host -> device, private -> pool); the values come from p.data
+            n_old = old["m"].numel()
+            m[:n_old].copy_(old["m"])
+            v[:n_old].copy_(old["v"])
         offs = []
         for p, n, off in zip(self._params, sizes, starts):
             view = _phys_view(data, off, tuple(p.shape))
@@ -157,3 +171,99 @@ class FlatAdam(torch.optim.Optimizer):
             for k, v in sg.items():
                 if k != "params":
                     g[k] = v
+
+
+class ParamPool:
+    """The same optimizer kind (generator / discriminator / council discriminator) of SEVERAL council members in ONE
+    flat storage: member k's FlatAdam buffers are slice k of the pool's data / grad / exp_avg / exp_avg_sq tensors, all
+    slices `stride` elements long (a multiple of 32).  The members have identical architectures, so a parameter sits at the
+    same offset in every slice -- which is what lets ONE kernel launch serve the same layer of all members (cg_group in
+    include/council_gan_hip.h: member z's weights = member 0's pointer + z * stride) and one Adam / zero-fill / fp16-split
+    launch serve all members.  The per-member FlatAdam objects stay the public optimizers (state_dict, param_groups,
+    schedulers, checkpoints: trainer_council.py:139-183, 969-992)."""
+
+    def __init__(self, opts):
+        self.opts = list(opts)
+        lay = [o.layout() for o in self.opts]
+        if any(l[0] != lay[0][0] for l in lay):
+            raise ValueError("council members must have identical parameter layouts to share a pool")
+        self.stride = lay[0][2]
+        self.data = self.grad = self.m = self.v = None
+        self.split = None            # ops.SplitWeights of the pool (set by the trainer when the split datapath is on)
+        for k, o in enumerate(self.opts):
+            o._pool, o._pool_index = self, k
+
+    def materialize(self, device):
+        device = torch.device(device)
+        if self.data is not None and self.data.device == device:
+            return
+        n = len(self.opts) * self.stride
+        self.data, self.grad, self.m, self.v = (torch.zeros(n, dtype=torch.float32, device=device) for _ in range(4))
+        for k, o in enumerate(self.opts):
+            sl = slice(k * self.stride, (k + 1) * self.stride)
+            o.materialize(device, storage=(self.data[sl], self.grad[sl], self.m[sl], self.v[sl]))
+            for p in o._params:
+                p._cg_pool = self
+
+    @property
+    def version(self):
+        return sum(o.version for o in self.opts)
+
+    def index_of(self, param):
+        """(member index in the pool, parameter index) of a parameter tensor, or None."""
+        key = id(param)
+        tab = self.__dict__.get('_index')
+        if tab is None:
+            tab = {id(p): (k, i) for k, o in enumerate(self.opts) for i, p in enumerate(o._params)}
+            self.__dict__['_index'] = tab
+        return tab.get(key)
+
+    def zero_grad(self, k0=0, n=None):
+        """Zero the gradient slices of members [k0, k0+n) with one fill."""
+        n = len(self.opts) - k0 if n is None else n
+        g = self.grad[k0 * self.stride:(k0 + n) * self.stride]
+        if g.is_cuda:
+            check(hip.load().cg_fill(ptr(g), g.numel(), 0.0, stream()), "cg_fill")
+        else:
+            g.zero_()
+        for o in self.opts[k0:k0 + n]:
+            for p in o._params:
+                p._cg_grad._cg_touched = False
+                p.grad = p._cg_grad
+
+    @torch.no_grad()
+    def step(self, k0=0, n=None, lockstep=False):
+        """Adam step of members [k0, k0+n).  `lockstep`: the members were updated by member-batched launches that only
+        flagged the FIRST member's gradient views as written -- its pattern holds for all of them; one launch per run of
+        touched parameters serves every member (their slices are `stride` apart)."""
+        n = len(self.opts) - k0 if n is None else n
+        opts = self.opts[k0:k0 + n]
+        lead = opts[0]
+        same = lockstep and all(o._steps == lead._steps and o.param_groups[0]['lr'] == lead.param_groups[0]['lr']
+                                for o in opts[1:])
+        if not same or n == 1:
+            if lockstep:
+                for o in opts[1:]:
+                    for p, q in zip(o._params, lead._params):
+                        p._cg_grad._cg_touched = q._cg_grad._cg_touched
+            for o in opts:
+                o.step()
+            return
+        f = lead.flat
+        grp = lead.param_groups[0]
+        b1, b2 = grp["betas"]
+        lib = hip.load()
+        for i0, i1 in lead.touched_runs():
+            off = f["offs"][i0]
+            cnt = f["offs"][i1 - 1] + f["sizes"][i1 - 1] - off
+            step = lead._steps[i0] + 1
+            base = k0 * self.stride + off
+            sl = slice(base, base + cnt)
+            check(lib.cg_adam_step_g(ptr(self.data[sl]), ptr(self.grad[sl]), ptr(self.m[sl]), ptr(self.v[sl]), cnt, n,
+                                     self.stride, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
+                                     float(grp["weight_decay"]), step, stream()), "cg_adam_step_g")
+            for o in opts:
+                for k in range(i0, i1):
+                    o._steps[k] = step
+        for o in opts:
+            o.version += 1

@@ -144,6 +144,17 @@ class CouncilShard:
                 out[m] = local_images[k] if r == me else recv[r, k].permute(0, 3, 1, 2)
         return out
 
+    def exchange_flat(self, local):
+        """`local`: this rank's members' comparison images as ONE member-major tensor [per_rank * B, C, H, W] (logical
+        NCHW, channels_last).  Returns every member's images as one member-major tensor [council_size * B, C, H, W] (of this
+        rank's batch slice): block m = member m.  One rank: the input itself, no copy, no collective."""
+        if self.world_size == 1:
+            return local
+        send = local.permute(0, 2, 3, 1).contiguous()                 # the PHYSICAL (NHWC) layout, untouched
+        recv = torch.empty((self.slice_ranks,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+        _all_gather(recv, send, self.slice_group)
+        return recv.view((-1,) + tuple(send.shape[1:])).permute(0, 3, 1, 2)
+
     def gather_scalars(self, values):
         """values: list of council_size floats with only the local entries meaningful -> full list
         (logging only; off the hot path).  Replicas of a member contribute their batch-slice values' mean."""

@@ -33,7 +33,7 @@ import torch.nn as nn
 from . import hip, ops
 from .hip import check, ptr, stream
 from .networks import AdaINGen, MsImageDis, MsImageDisCouncil
-from .optim import FlatAdam
+from .optim import FlatAdam, ParamPool
 from .parallel import CouncilShard
 from .utils import get_model_list, get_scheduler, weights_init
 
@@ -181,6 +181,8 @@ class Council_Trainer(nn.Module):
         # encode the SAME batch with the SAME generator weights, so the encoder runs once per iteration
         self._img_cache = {}
         self._enc_cache = {}
+        self._rep_cache = {}
+        self._const_cache = {}
         self._streams = []
         # datapath of the convolutions with >= 32 channels -- forward, data-gradient and weight-gradient, generators and
         # both discriminators: "split" = fp16 x 3 MFMA on {hi, lo} fp16 operand planes (22 significand bits -- error
@@ -201,29 +203,35 @@ class Council_Trainer(nn.Module):
         torch.cuda.set_device(dev)
         hip.load()
         self.s_a, self.s_b = self.s_a.to(dev), self.s_b.to(dev)
-        for i in self.shard.local:       # non-local members stay on the host, untouched
+        local = self.shard.local
+        for i in local:                  # non-local members stay on the host, untouched
             for d in self._dirs:
                 for kind in ('gen', 'dis') + (('disc',) if self.do_dis_council else ()):
                     net = self._nets(kind, d)[i]
                     for b in net.buffers():
                         b.data = b.data.to(dev)
-            self.gen_opt_s[i].materialize(dev)
-            self.dis_opt_s[i].materialize(dev)
-            if self.do_dis_council:
-                self.dis_council_opt_s[i].materialize(dev)
-        self._rings = {d: {i: (torch.ones(self._ring_n, device=dev), torch.ones(self._ring_n, device=dev),
-                               torch.ones(1, device=dev))
-                           for i in self.shard.local} for d in self._dirs}
+        # One pool per optimizer kind over this rank's members: member k's parameters / gradients / Adam moments are slice
+        # k of the pool's flat tensors, at a uniform stride -- the layout member-batched launches address (optim.ParamPool)
+        self._pools = {'gen': ParamPool([self.gen_opt_s[i] for i in local]),
+                       'dis': ParamPool([self.dis_opt_s[i] for i in local])}
+        if self.do_dis_council:
+            self._pools['disc'] = ParamPool([self.dis_council_opt_s[i] for i in local])
+        for pool in self._pools.values():
+            pool.materialize(dev)
+        L = len(local)
+        self._rings = {d: (torch.ones(L * self._ring_n, device=dev), torch.ones(L * self._ring_n, device=dev),
+                           torch.ones(L, device=dev)) for d in self._dirs}
         self._device = dev
-        # split-precision datapath: one lazily refreshed {hi, lo} fp16 copy of every optimizer's flat weight buffer
+        # split-precision datapath: one lazily refreshed {hi, lo} fp16 copy of every pool's flat weight storage
         # (generators: instance-normalised activations travel unscaled; discriminators and all gradients: per-tensor
         # power-of-two scales chosen on the device)
         ops.X3_FORWARD = ops.X3_BACKWARD = ops.X3_DYNAMIC_INPUT = self._split_fwd
         if self._split_fwd:
-            for i in self.shard.local:
-                for kind, opt in (('gen', self.gen_opt_s[i]), ('dis', self.dis_opt_s[i])) + \
-                        ((('disc', self.dis_council_opt_s[i]),) if self.do_dis_council else ()):
-                    mgr = ops.SplitWeights(opt)
+            for kind, pool in self._pools.items():
+                mgr = ops.SplitWeights(pool)
+                pool.split = mgr
+                for k, i in enumerate(local):
+                    opt = pool.opts[k]
                     for d in self._dirs:
                         net = self._nets(kind, d)[i]
                         for m in net.modules():
@@ -231,12 +239,39 @@ class Council_Trainer(nn.Module):
                         # a checkpoint load rewrites the weights behind the optimizer's back: invalidate the copies
                         net.register_load_state_dict_post_hook(
                             lambda module, keys, _opt=opt: setattr(_opt, 'version', _opt.version + 1))
-        # Council members are independent models: each local member's kernels go to its own HIP stream, so the
-        # low-occupancy launches of one member (16x16 / 8x8 discriminator layers, 1-block-per-CU convs) overlap with
-        # another member's work.  CG_MEMBER_STREAMS=1 serialises everything on the caller's stream.
-        n = min(int(os.environ.get('CG_MEMBER_STREAMS', '2')), len(self.shard.local))
+        # Member-batched execution (default): this rank's members run every layer as ONE launch, `CG_GROUP` members at a
+        # time (default 4; the 31-bit buffer offsets of the kernels bound the batched tensors, _plan_groups).  CG_GROUP=1
+        # walks the members one by one like the reference's loops (trainer_council.py:328,558,747,826,858); then each
+        # member's kernels go to one of CG_MEMBER_STREAMS HIP streams so that low-occupancy launches overlap.
+        self._group_max = max(1, int(os.environ.get('CG_GROUP', '4')))
+        self._groups = None
+        n = min(int(os.environ.get('CG_MEMBER_STREAMS', '2')), L)
         self._streams = [torch.cuda.Stream(device=dev) for _ in range(n)] if n > 1 else []
         return self
+
+    def _plan_groups(self, x):
+        """Split this rank's members into runs of consecutive members that execute as one launch.  The largest batched
+        tensor (the council discriminator's first full-resolution feature map: (1 + colleagues) * B samples per member,
+        dis.dim channels) must stay below 2 GiB -- the kernels address operands with 31-bit byte offsets."""
+        key = tuple(x.shape)
+        if self._groups is not None and self._groups[0] == key:
+            return self._groups[1]
+        local = self.shard.local
+        B, _, H, W = x.shape
+        hp = self.__dict__.get('_hp_last') or {}
+        n_rel = hp.get('council', {}).get('numberOfCouncil_dis_relative_iteration', 0) if hp else 0
+        u = min(n_rel, self.council_size - 1) if self.do_dis_council else 0
+        width = max(self._nets('dis', self._dirs[0])[local[0]].dim, 64)
+        per_member = max((1 + u) * B, 2 * B) * width * H * W * 4
+        g = 1
+        for cand in range(1, len(local) + 1):
+            if len(local) % cand == 0 and cand <= self._group_max and cand * per_member < (1 << 31):
+                g = cand
+        if self.shard.dp > 1:
+            g = 1
+        groups = [local[k:k + g] for k in range(0, len(local), g)]
+        self._groups = (key, groups)
+        return groups
 
     def _fork(self):
         """Member streams start after everything already queued on the caller's stream."""
@@ -250,8 +285,9 @@ class Council_Trainer(nn.Module):
         for st in self._streams:
             cur.wait_stream(st)
 
-    def _on(self, i):
-        if not self._streams:
+    def _on(self, i, groups=None):
+        """Stream context of the group led by member i (nothing to overlap when one group holds every member)."""
+        if not self._streams or (groups is not None and len(groups) == 1):
             return contextlib.nullcontext()
         return torch.cuda.stream(self._streams[self.shard.local.index(i) % len(self._streams)])
 
@@ -299,25 +335,48 @@ class Council_Trainer(nn.Module):
         finally:
             dec.split_active = False
 
-    def _weights_version(self, d, i):
-        gen = self._nets('gen', d)[i]
-        return (self.gen_opt_s[i].version, sum(p._version for p in gen.enc_content.parameters()))
+    def _weights_version(self, d, grp):
+        opts = [self.gen_opt_s[i] for i in grp]
+        gen = self._nets('gen', d)[grp[0]]
+        return (tuple(o.version for o in opts), sum(p._version for p in gen.enc_content.parameters()))
 
-    def _content(self, d, i, x, need_grad):
-        """Content code of member i for batch x (the NHWC device copy from _img).  Encoded once per (batch,
-        generator weights) with the autograd tape attached; the discriminator updates use it detached, gen_update
-        back-propagates through it (and drops it, the tape being consumed)."""
-        key = (id(x), self._weights_version(d, i))
-        ent = self._enc_cache.get((d, i))
+    def _rep(self, x, g):
+        """The batch repeated once per member of a launch (member-major): every member sees the same images."""
+        if g == 1:
+            return x
+        key = (id(x), g)
+        ent = self._rep_cache.get(key)
+        if ent is None or ent[0] is not x:
+            if len(self._rep_cache) > 8:
+                self._rep_cache.clear()
+            ent = (x, ops.take_rows(x, None, list(range(x.shape[0])) * g))
+            self._rep_cache[key] = ent
+        return ent[1]
+
+    def _content(self, d, grp, x, need_grad):
+        """Content codes of the members of `grp` for batch x (the member-major repetition of the NHWC device copy from
+        _img).  Encoded once per (batch, generator weights) with the autograd tape attached; the discriminator updates
+        use it detached, gen_update back-propagates through it (and drops it, the tape being consumed)."""
+        key = (id(x), self._weights_version(d, grp))
+        slot = (d, grp[0], len(grp))
+        ent = self._enc_cache.get(slot)
         if ent is None or ent[0] != key or ent[1] is not x:
             with torch.enable_grad():
-                content = self._nets('gen', d)[i].encode_content(x)
+                content = self._nets('gen', d)[grp[0]].encode_content(x)
             ent = (key, x, content)
-            self._enc_cache[(d, i)] = ent
+            self._enc_cache[slot] = ent
         if need_grad:
-            del self._enc_cache[(d, i)]
+            del self._enc_cache[slot]
             return ent[2]
         return ent[2].detach()
+
+    def _const(self, value, n):
+        """Device vector of n copies of `value` (upstream gradients of the per-member loss vectors), cached."""
+        key = (float(value), n)
+        t = self._const_cache.get(key)
+        if t is None:
+            t = self._const_cache[key] = torch.full((n,), float(value), dtype=torch.float32, device=self._device)
+        return t
 
     def _noise(self, n):
         # CPU RNG then upload, exactly as the reference (trainer_council.py:284-285,741,744,807-809)
@@ -334,10 +393,10 @@ class Council_Trainer(nn.Module):
         v = loss.detach()
         return self.shard.replica_mean_(v.clone()) if self.shard.dp > 1 else v
 
-    def _sync_grads(self, opt):
-        """Full-batch gradient = mean of the member replicas' gradients: one all-reduce of the flat buffer."""
+    def _sync_grads(self, pool, k0, g):
+        """Full-batch gradient = mean of the member replicas' gradients: one all-reduce of the members' gradient slices."""
         if self.shard.dp > 1:
-            self.shard.replica_mean_(opt.flat['grad'])
+            self.shard.replica_mean_(pool.grad[k0 * pool.stride:(k0 + g) * pool.stride])
 
     def _upload(self, t):
         """Host tensor -> device without stalling the host: a pageable-memory copy blocks until the stream has drained,
@@ -375,46 +434,60 @@ class Council_Trainer(nn.Module):
     # dis_update, trainer_council.py:735-780
     # ------------------------------------------------------------------------------------
     def dis_update(self, x_a=None, x_b=None, hyperparameters=None):
-        hp = hyperparameters
+        hp = self._hp_last = hyperparameters
         self._ready()
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}      # source image per direction
         tgt = {'a2b': x['b2a'], 'b2a': x['a2b']}                 # real image of the target domain
-        for i in self.shard.local:
-            self.dis_opt_s[i].zero_grad()
+        groups = self._plan_groups(x[self._dirs[0]])
+        pool = self._pools['dis']
+        pool.zero_grad()
         s = {}
         if self.do_a2b_conf:
-            s['a2b'] = self._upload(self._style(x_b.size(0)))
+            s['a2b'] = self._style(x_b.size(0))
             self.loss_dis_a2b_s = [0] * self.council_size
         if self.do_b2a_conf:
-            s['b2a'] = self._upload(self._style(x_a.size(0)))
+            s['b2a'] = self._style(x_a.size(0))
             self.loss_dis_b2a_s = [0] * self.council_size
         self.loss_dis_total_s = [0] * self.council_size
+        s_dev = {}
         self._fork()
-        for i in self.shard.local:
-            with self._on(i):
-                total = None
+        for grp in groups:
+            g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
+            with self._on(lead, groups), ops.members(g):
+                losses, ups = [], []
                 for d in self._dirs:
-                    gen = self._nets('gen', d)[i]
-                    content = self._content(d, i, x[d], need_grad=False)
-                    with torch.no_grad(), self._split_decode(d, i):
-                        x_fake = gen.decode(content, s[d], x[d])
-                    # :775-777 -- only the a2b term is scaled by gan_w (reference quirk, kept); the scale is
-                    # folded into the per-sample loss weights
+                    gen = self._nets('gen', d)[lead]
+                    if (d, g) not in s_dev:
+                        s_dev[(d, g)] = self._upload(s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
+                    xr = self._rep(x[d], g)
+                    content = self._content(d, grp, xr, need_grad=False)
+                    with torch.no_grad(), self._split_decode(d, lead):
+                        x_fake = gen.decode(content, s_dev[(d, g)], xr)
+                    # :775-777 -- only the a2b term is scaled by gan_w (reference quirk, kept): the unscaled loss is what
+                    # train.py logs, the scale rides on the upstream gradient
                     w = float(hp['gan_w']) if d == 'a2b' else 1.0
-                    l = self._nets('dis', d)[i].calc_dis_loss(x_fake, tgt[d], weight=w)
-                    getattr(self, 'loss_dis_%s_s' % d)[i] = l.detach() / w if w != 1.0 else l.detach()
-                    total = l if total is None else total + l
-                self.loss_dis_total_s[i] = total.detach()
-                total.backward()
-                self._sync_grads(self.dis_opt_s[i])
-                self.dis_opt_s[i].step()
+                    l = self._nets('dis', d)[lead].calc_dis_loss(x_fake, tgt[d]).view(-1)       # one loss per member
+                    losses.append(l)
+                    ups.append(self._const(w, g))
+                    for m, i in enumerate(grp):
+                        getattr(self, 'loss_dis_%s_s' % d)[i] = l.detach()[m]
+                torch.autograd.backward(losses, ups)          # members and directions own disjoint parameters
+                for m, i in enumerate(grp):
+                    tot = None
+                    for d, l in zip(self._dirs, losses):
+                        w = float(hp['gan_w']) if d == 'a2b' else 1.0
+                        t = l.detach()[m] if w == 1.0 else l.detach()[m] * w
+                        tot = t if tot is None else tot + t
+                    self.loss_dis_total_s[i] = tot
+                self._sync_grads(pool, k0, g)
+                pool.step(k0, g, lockstep=g > 1)
         self._join()
 
     # ------------------------------------------------------------------------------------
     # dis_council_update, trainer_council.py:782-883
     # ------------------------------------------------------------------------------------
     def dis_council_update(self, x_a=None, x_b=None, hyperparameters=None):
-        hp = hyperparameters
+        hp = self._hp_last = hyperparameters
         c = hp['council']
         if self.council_size <= 1 or c['numberOfCouncil_dis_relative_iteration'] == 0:
             print('no council discriminetor is needed (council size <= 1 or numberOfCouncil_dis_relative_iteration == 0)')
@@ -426,67 +499,80 @@ class Council_Trainer(nn.Module):
             return
         self._ready()
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}
-        for i in self.shard.local:
-            self.dis_council_opt_s[i].zero_grad()
+        groups = self._plan_groups(x[self._dirs[0]])
+        pool = self._pools['disc']
+        pool.zero_grad()
         s, s_less = {}, {}
         if self.do_b2a_conf:                       # s_a is drawn first here (:806-809)
             s['b2a'] = self._style(x_a.size(0))
         if self.do_a2b_conf:
             s['a2b'] = self._style(x_b.size(0))
         less = c['discriminetro_less_style_by']
-        for d in self._dirs:
-            if less != 0:
-                s_less[d] = self._upload(s[d] * less)
-            s[d] = self._upload(s[d])
         n_rel = c['numberOfCouncil_dis_relative_iteration']
+        L = len(self.shard.local)
 
-        x_full = {d: {} for d in self._dirs}
-        x_cmp_local = {d: [] for d in self._dirs}
+        # ---- every member's translation (full style) and comparison image (reduced style) ------------------------
+        x_full = {d: {} for d in self._dirs}                 # group lead -> the group's own translations [g*B]
+        x_cmp_local = {}
+        for d in self._dirs:
+            b = x[d].shape[0]
+            x_cmp_local[d] = torch.empty((L * b,) + tuple(x[d].shape[1:]), dtype=torch.float32, device=self._device,
+                                         memory_format=torch.channels_last)
+        s_dev = {}
         self._fork()
-        for i in self.shard.local:
-            with self._on(i):
+        for grp in groups:
+            g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
+            with self._on(lead, groups), ops.members(g):
                 for d in self._dirs:
-                    gen = self._nets('gen', d)[i]
-                    content = self._content(d, i, x[d], need_grad=False)
-                    with torch.no_grad(), self._split_decode(d, i):
+                    gen = self._nets('gen', d)[lead]
+                    b = x[d].shape[0]
+                    xr = self._rep(x[d], g)
+                    content = self._content(d, grp, xr, need_grad=False)
+                    with torch.no_grad(), self._split_decode(d, lead):
                         if less != 0:
-                            # the two translations differ only in the style code: one decode over 2B samples (every
-                            # operator of the decoder is per sample) -- twice the rows per launch, half the launches
-                            b = x[d].shape[0]
-                            both = gen.decode(torch.cat((content, content), 0), torch.cat((s[d], s_less[d]), 0),
-                                              torch.cat((x[d], x[d]), 0))
-                            x_full[d][i] = both[:b]
-                            x_cmp_local[d].append(both[b:])
+                            # the two translations differ only in the style code: one decode over 2B samples per member
+                            # (every operator of the decoder is per sample) -- twice the rows per launch, half the launches
+                            if (d, g) not in s_dev:
+                                s_dev[(d, g)] = self._upload(torch.cat((s[d], s[d] * less), 0).repeat(g, 1, 1, 1))
+                            twice = [m * b + r for m in range(g) for _ in range(2) for r in range(b)]
+                            both = gen.decode(ops.take_rows(content, None, twice), s_dev[(d, g)], self._rep(x[d], 2 * g))
+                            own = [m * 2 * b + r for m in range(g) for r in range(b)]
+                            x_full[d][lead] = ops.take_rows(both, None, own)
+                            ops.take_rows(both, None, [i + b for i in own], out=x_cmp_local[d][k0 * b:(k0 + g) * b])
                         else:
-                            x_full[d][i] = gen.decode(content, s[d], x[d])
-                            x_cmp_local[d].append(x_full[d][i])
+                            if (d, g) not in s_dev:
+                                s_dev[(d, g)] = self._upload(s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
+                            x_full[d][lead] = gen.decode(content, s_dev[(d, g)], xr)
+                            ops.take_rows(x_full[d][lead], None, list(range(g * b)), out=x_cmp_local[d][k0 * b:(k0 + g) * b])
         self._join()      # every member's council discriminator reads the OTHER members' images
-        # the ONE cross-member exchange (trainer_council.py:853-856): every member's comparison image
-        x_cmp = {d: self.shard.exchange(x_cmp_local[d]) for d in self._dirs}
+        # the ONE cross-member exchange (trainer_council.py:853-856): every member's comparison image, member-major
+        x_cmp = {d: self.shard.exchange_flat(x_cmp_local[d]) for d in self._dirs}
 
         self.loss_dis_council_a2b_s = [0] * self.council_size
         self.loss_dis_council_b2a_s = [0] * self.council_size
         self.loss_dis_council_total_s = [0] * self.council_size
         scale = float(hp['council_w']) / float(n_rel)                      # :878-880
-        self._fork()
-        for i in range(self.council_size):
-            picks = self.draw_colleagues(i, self.council_size, n_rel)     # every rank replays every member's draws
-            if i not in self.shard.local:
-                continue
-            uniq = sorted(set(picks))
-            mult = [float(picks.count(j)) for j in uniq]
-            with self._on(i):
-                total = None
+        picks = [self.draw_colleagues(i, self.council_size, n_rel) for i in range(self.council_size)]   # every rank replays
+        self._fork()                                                                                  # every member's draws
+        for grp in groups:
+            g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
+            pk = [[(j, float(picks[i].count(j))) for j in sorted(set(picks[i]))] for i in grp]
+            with self._on(lead, groups), ops.members(g):
+                losses = []
                 for d in self._dirs:
-                    l = self._nets('disc', d)[i].calc_dis_loss_multi(
-                        x_full[d][i], [x_cmp[d][j] for j in uniq], mult, x[d], fake_weight=float(len(picks)),
-                        weight=scale)
-                    getattr(self, 'loss_dis_council_%s_s' % d)[i] = l.detach() / scale
-                    total = l if total is None else total + l
-                self.loss_dis_council_total_s[i] = total.detach()
-                total.backward()
-                self._sync_grads(self.dis_council_opt_s[i])
-                self.dis_council_opt_s[i].step()
+                    l = self._nets('disc', d)[lead].calc_dis_loss_members(
+                        x_full[d][lead], x_cmp[d], pk, x[d], fake_weight=float(len(picks[lead])), weight=scale).view(-1)
+                    losses.append(l)
+                    for m, i in enumerate(grp):
+                        getattr(self, 'loss_dis_council_%s_s' % d)[i] = l.detach()[m] / scale
+                torch.autograd.backward(losses, [self._const(1.0, g)] * len(losses))
+                for m, i in enumerate(grp):
+                    tot = None
+                    for l in losses:
+                        tot = l.detach()[m] if tot is None else tot + l.detach()[m]
+                    self.loss_dis_council_total_s[i] = tot
+                self._sync_grads(pool, k0, g)
+                pool.step(k0, g, lockstep=g > 1)
         self._join()
 
     @staticmethod
@@ -508,15 +594,16 @@ class Council_Trainer(nn.Module):
     # gen_update, trainer_council.py:280-634
     # ------------------------------------------------------------------------------------
     def gen_update(self, x_a, x_b, hyperparameters, iterations=0):
-        hp = hyperparameters
+        hp = self._hp_last = hyperparameters
         self.hyperparameters = hp
         self._ready()
         lib = hip.load()
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}
-        for i in self.shard.local:
-            self.gen_opt_s[i].zero_grad()
-        s_a = self._upload(self._style(x_a.size(0)))     # both drawn, s_a first (:284-285)
-        s_b = self._upload(self._style(x_b.size(0)))
+        groups = self._plan_groups(x[self._dirs[0]])
+        pool = self._pools['gen']
+        pool.zero_grad()
+        s_a = self._style(x_a.size(0))     # both drawn, s_a first (:284-285)
+        s_b = self._style(x_b.size(0))
         s = {'a2b': s_b, 'b2a': s_a}
         fl = hp['focus_loss']
         focus_live = hp['iteration'] > fl['focus_loss_start_at_iter']
@@ -554,56 +641,79 @@ class Council_Trainer(nn.Module):
                         if p.requires_grad:
                             p.requires_grad_(False)
                             frozen.append(p)
+        s_dev = {}
+        n_ring = self._ring_n
         self._fork()
         try:
-            for i in self.shard.local:
-                with self._on(i):
-                    total = None
+            for grp in groups:
+                g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
+                with self._on(lead, groups), ops.members(g):
+                    roots, ups, totals = [], [], []
                     for d in self._dirs:
-                        gen = self._nets('gen', d)[i]
-                        x_fake = gen.decode(self._content(d, i, x[d], need_grad=True), s[d], x[d])
+                        gen = self._nets('gen', d)[lead]
+                        if (d, g) not in s_dev:
+                            s_dev[(d, g)] = self._upload(s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
+                        xr = self._rep(x[d], g)
+                        x_fake = gen.decode(self._content(d, grp, xr, need_grad=True), s_dev[(d, g)], xr)
                         mask = gen.dec.mask_s
-                        terms = []
+                        ftot = adv = lc = w_dev = None
                         if focus_on:                                                   # :390-451
                             ftot, parts = ops.focus_loss(mask, fl['mask_zero_or_one_center'], fl['mask_zero_or_one_epsilon'],
                                                          hp['mask_zero_or_one_w'], hp['mask_total_w'], hp['mask_tv_w'],
                                                          fl['mask_small_use_abs'], fl['mask_small_use_square'],
                                                          reduce=self.shard.replica_mean_ if self.shard.dp > 1 else None)
-                            terms.append(ftot)
-                            if hp['mask_zero_or_one_w'] != 0:
-                                getattr(self, 'loss_gen_mask_zero_one_%s_s' % ab[d])[i] = parts[0]
-                            if hp['mask_total_w'] != 0:
-                                getattr(self, 'loss_gen_mask_total_%s_s' % ab[d])[i] = parts[1]
-                            if hp['mask_tv_w'] != 0:
-                                getattr(self, 'loss_gen_mask_TV_%s_s' % ab[d])[i] = parts[2]
+                            roots.append(ftot.view(-1))
+                            ups.append(self._const(1.0, g))
+                            parts = parts.view(g, 3)
+                            for m, i in enumerate(grp):
+                                if hp['mask_zero_or_one_w'] != 0:
+                                    getattr(self, 'loss_gen_mask_zero_one_%s_s' % ab[d])[i] = parts[m, 0]
+                                if hp['mask_total_w'] != 0:
+                                    getattr(self, 'loss_gen_mask_total_%s_s' % ab[d])[i] = parts[m, 1]
+                                if hp['mask_tv_w'] != 0:
+                                    getattr(self, 'loss_gen_mask_TV_%s_s' % ab[d])[i] = parts[m, 2]
+                        ring_g, ring_c, w_all = self._rings[d]
+                        rg = ring_g[k0 * n_ring:(k0 + g) * n_ring]
+                        rc = ring_c[k0 * n_ring:(k0 + g) * n_ring]
                         if hp['gan_w'] != 0:                                           # :498-529
-                            adv = self._nets('dis', d)[i].calc_gen_loss(x_fake)
+                            adv = self._nets('dis', d)[lead].calc_gen_loss(x_fake).view(-1)
                             adv_full = self._full_batch(adv)
-                            getattr(self, 'loss_gen_adv_%s_s' % d)[i] = adv_full
-                            ring_g, ring_c, w_dev = self._rings[d][i]
+                            for m, i in enumerate(grp):
+                                getattr(self, 'loss_gen_adv_%s_s' % d)[i] = adv_full[m]
                             if self.do_w_loss_matching:
-                                check(lib.cg_ring_push(ptr(ring_g), self._ring_n, self._ring_pos[d][i], ptr(adv_full),
-                                                       stream()), "cg_ring_push")
-                                self._ring_pos[d][i] += 1
-                            terms.append(adv * float(hp['gan_w']))
+                                check(lib.cg_ring_push_g(ptr(rg), n_ring, self._ring_pos[d][lead], ptr(adv_full), g, stream()),
+                                      "cg_ring_push")
+                                for i in grp:
+                                    self._ring_pos[d][i] += 1
+                            roots.append(adv)
+                            ups.append(self._const(float(hp['gan_w']), g))
                         if council_on:                                                 # :558-624
-                            lc = self._nets('disc', d)[i].calc_gen_loss(x_fake, x[d])
+                            lc = self._nets('disc', d)[lead].calc_gen_loss(x_fake, xr).view(-1)
                             if self.do_w_loss_matching:
-                                ring_g, ring_c, w_dev = self._rings[d][i]
-                                check(lib.cg_loss_match(ptr(ring_g), ptr(ring_c), self._ring_n, self._ring_pos_c[d][i],
-                                                        ptr(self._full_batch(lc)), ptr(w_dev), stream()), "cg_loss_match")
-                                self._ring_pos_c[d][i] += 1
+                                w_dev = w_all[k0:k0 + g]
+                                check(lib.cg_loss_match_g(ptr(rg), ptr(rc), n_ring, self._ring_pos_c[d][lead],
+                                                          ptr(self._full_batch(lc)), ptr(w_dev), g, stream()), "cg_loss_match")
+                                for i in grp:
+                                    self._ring_pos_c[d][i] += 1
                                 setattr(self, 'w_match_%s_conf' % d, w_dev[0])
-                                lc = lc * w_dev[0]
-                            lc = lc * float(hp['council_w'])
-                            getattr(self, 'council_loss_%s_s' % ab[d])[i] = lc.detach()
-                            terms.append(lc)
-                        for t in terms:
-                            total = t if total is None else total + t
-                    self.loss_gen_total_s[i] = total.detach()
-                    total.backward()
-                    self._sync_grads(self.gen_opt_s[i])
-                    self.gen_opt_s[i].step()
+                        # per-member objective + the upstream gradient of the council term (council_w x matching weight)
+                        total, council, gcouncil = ops.gen_total(ftot, adv.detach() if adv is not None else None,
+                                                                 lc.detach() if lc is not None else None, w_dev,
+                                                                 hp['gan_w'], hp['council_w'], g)
+                        if council_on:
+                            roots.append(lc)
+                            ups.append(gcouncil)
+                            for m, i in enumerate(grp):
+                                getattr(self, 'council_loss_%s_s' % ab[d])[i] = council[m]
+                        totals.append(total)
+                    for m, i in enumerate(grp):
+                        tot = None
+                        for t in totals:
+                            tot = t[m] if tot is None else tot + t[m]
+                        self.loss_gen_total_s[i] = tot
+                    torch.autograd.backward(roots, ups)
+                    self._sync_grads(pool, k0, g)
+                    pool.step(k0, g, lockstep=g > 1)
         finally:
             self._join()
             for p in frozen:

@@ -61,6 +61,18 @@ typedef struct cg_conv_geom {
     int8_t dx[CG_MAX_TAPS];
 } cg_conv_geom;
 
+/* Member-batched ("grouped") launches: the SAME layer of `n` council members as one launch.  The members' activations
+ * are consecutive sample blocks of one batched NHWC tensor (member z owns samples [z*N/n, (z+1)*N/n) of every activation /
+ * gradient tensor, geometry N = all members' samples); their parameters -- weights, biases and the gradients of both --
+ * sit `stride` fp32 ELEMENTS apart (one pool per optimizer kind; for split {hi, lo} weights the same stride in elements,
+ * a multiple of 32).  Pointers name member 0's tensors.  NULL or n == 1: an ordinary call.  Replaces the reference's
+ * sequential member loops (trainer_council.py:328,558,747,826,858): members are independent models. */
+typedef struct cg_group {
+    int32_t n;
+    int32_t reserved;
+    int64_t stride;
+} cg_group;
+
 const char* cg_last_error(void);
 int cg_version(void);
 
@@ -99,11 +111,17 @@ int cg_conv2d_fwd_x3(const cg_conv_geom* g, const void* x_hi, size_t x_lo_elems,
                      float w_scale, const float* x_scale_dev, const float* bias, float* y, void* y_split,
                      size_t y_lo_elems, double* stats, size_t stats_bytes, int* rows_per_partial, int tile_cfg,
                      float* amax_state, int* amax_nslots, cg_stream_t stream);
-/* The same layer of n <= 4 council members (one geometry; per-member activations, weights, bias, output, optional
- * device-side scales) as ONE launch -- tables of n pointers.  Experimental (member-batched execution). */
-int cg_conv2d_fwd_x3_group(int n, const cg_conv_geom* g, const void* const* x_hi, size_t x_lo_elems,
-                           const void* const* w_hi, size_t w_lo_elems, float w_scale, const float* const* x_scale_dev,
-                           const float* const* bias, float* const* y, int tile_cfg, cg_stream_t stream);
+/* Grouped / general form.  w_scale_dev: device-side power-of-two scale the weights were split with
+ * (cg_split_f16_dynamic_capped; multiplies the static w_scale; NULL = static only). */
+int cg_conv2d_fwd_x3_g(const cg_conv_geom* g, const cg_group* group, const void* x_hi, size_t x_lo_elems, const void* w_hi,
+                       size_t w_lo_elems, float w_scale, const float* w_scale_dev, const float* x_scale_dev,
+                       const float* bias, float* y, void* y_split, size_t y_lo_elems, double* stats, size_t stats_bytes,
+                       int* rows_per_partial, int tile_cfg, float* amax_state, int* amax_nslots, cg_stream_t stream);
+/* fp32 forward, grouped / general form: instance-norm partials (stats, rows_per_partial) and per-block output maxima
+ * (amax_state, amax_nslots) are optional services, NULL = off (cg_conv2d_fwd_stats / cg_conv2d_fwd_amax semantics). */
+int cg_conv2d_fwd_g(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2, const float* w,
+                    const float* bias, float* y, double* stats, size_t stats_bytes, int* rows_per_partial,
+                    float* amax_state, int* amax_nslots, cg_stream_t stream);
 /* amax_state / amax_nslots (both or neither): the epilogue leaves max|y| per block in amax_state[2 .. 2 + *amax_nslots)
  * (a CG_SPLIT_STATE_FLOATS buffer) for cg_split_f16_dynamic(y, ..., state, nslots), which then skips its own reduction
  * pass over y (launches with more than 1024 blocks share 1024 slots through an atomic max); *amax_nslots = 0 when the
@@ -120,6 +138,11 @@ int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, f
                          cg_stream_t stream);   /* nslots > 0: a producer kernel already left that many per-block maxima
                                                    in state[2..] (cg_instnorm_bwd, cg_conv2d_fwd_amax, cg_conv2d_fwd_x3);
                                                    0: measure here */
+/* The same with the scale capped: scale = min(max_scale, 2^(5 - floor(log2 max|x|))), max_scale a power of two (0 = no
+ * cap).  Used for the WEIGHTS of an optimizer pool with max_scale = CG_X3_WSCALE: ordinary weights (|w| <= 1/16) keep
+ * the static 2^10, larger ones (a loaded checkpoint) get the smaller scale that keeps their hi halves finite. */
+int cg_split_f16_dynamic_capped(const float* x, void* out, size_t n, size_t lo_elems, float* state, int nslots,
+                                float max_scale, cg_stream_t stream);
 /* dz = dy * act'(y) straight into split form (cg_act_bwd + cg_split_f16_dynamic without the fp32 round trip); dz
  * (optional) additionally receives the fp32 values */
 int cg_act_bwd_split(const float* dy, const float* y, size_t n, int act, void* out, size_t lo_elems, float* state,
@@ -128,6 +151,18 @@ int cg_act_bwd_split(const float* dy, const float* y, size_t n, int act, void* o
  * ws: cg_conv2d_dgrad_workspace(g, nci) bytes (holds the re-laid-out, split weights) */
 int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, size_t dz_lo_elems, const float* dz_scale_dev,
                        const float* w, int ci0, int nci, float* dx, void* ws, size_t ws_bytes, cg_stream_t stream);
+/* The two halves of it, so that the re-laid-out weights are prepared ONCE per weight version instead of once per launch
+ * (grouped: all members in one call):
+ *   _prep: w [Cout][T][Cin] fp32 of every member -> {hi, lo} planes of scale*w in the per-class [ci][tc][co] layout the
+ *          data-gradient kernel reads; member m at wt + 4*m*cg_conv2d_dgrad_x3_wt_elems(g, nci) bytes.
+ *          scale = w_scale, times the device-side *w_scale_dev when given.
+ *   _run:  dx from dz and the prepared weights (same w_scale / w_scale_dev). */
+size_t cg_conv2d_dgrad_x3_wt_elems(const cg_conv_geom* g, int nci);
+int cg_conv2d_dgrad_x3_prep(const cg_conv_geom* g, const cg_group* group, const float* w, int ci0, int nci, float w_scale,
+                            const float* w_scale_dev, void* wt, size_t wt_bytes, cg_stream_t stream);
+int cg_conv2d_dgrad_x3_run(const cg_conv_geom* g, const cg_group* group, const void* dz_split, size_t dz_lo_elems,
+                           const float* dz_scale_dev, const void* wt, float w_scale, const float* w_scale_dev, int ci0,
+                           int nci, float* dx, cg_stream_t stream);
 /* split-precision weight gradient: cg_conv2d_wgrad with x and dz given in {hi, lo} form (+ device-side scales,
  * NULL = 1).  cg_conv2d_wgrad_x3_ok(g) != 0 iff the layer qualifies (one source, every k-tile inside one tap,
  * channel counts multiples of 32, power-of-two output plane); workspace as cg_conv2d_wgrad_workspace(g). */
@@ -135,6 +170,10 @@ int cg_conv2d_wgrad_x3_ok(const cg_conv_geom* g);
 int cg_conv2d_wgrad_x3(const cg_conv_geom* g, const void* x_split, size_t x_lo_elems, const float* x_scale_dev,
                        const void* dz_split, size_t dz_lo_elems, const float* dz_scale_dev, float* dw, float* dbias,
                        int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream);
+int cg_conv2d_wgrad_x3_ok_g(const cg_conv_geom* g, const cg_group* group);
+int cg_conv2d_wgrad_x3_g(const cg_conv_geom* g, const cg_group* group, const void* x_split, size_t x_lo_elems,
+                         const float* x_scale_dev, const void* dz_split, size_t dz_lo_elems, const float* dz_scale_dev,
+                         float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream);
 /* y_split of cg_conv2d_fwd_x3 (optional): the output ALSO in {hi, lo} form for a convolution that consumes it next */
 /* instance norm / AdaIN apply that writes the split form of its output (and / or fp32): the producer side of
  * cg_conv2d_fwd_x3.  y may be NULL (split only); y_split holds N*HW*C {hi, lo} pairs in the layout above. */
@@ -152,6 +191,11 @@ int cg_conv2d_fwd_tile(const cg_conv_geom* g, const float* x1, const float* x2, 
 size_t cg_conv2d_wgrad_workspace(const cg_conv_geom* g);
 int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const float* x2, const float* dz, float* dw,
                     float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream);
+/* grouped: member z's gradient goes to dw + z*stride (dbias likewise); a member's split plan and summation order do not
+ * depend on the number of members in the launch */
+size_t cg_conv2d_wgrad_workspace_g(const cg_conv_geom* g, const cg_group* group);
+int cg_conv2d_wgrad_g(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2, const float* dz,
+                      float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream);
 
 /* dx (w.r.t. input channels [ci0, ci0+nci) of the convolution described by the FORWARD geometry g) from
  * dz [N, Ho, Wo, Cout]; dx is the dense [N, H<<up, W<<up, nci] tensor at the resolution the taps see (a nearest-2x
@@ -160,6 +204,9 @@ int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const float* x2, con
 size_t cg_conv2d_dgrad_workspace(const cg_conv_geom* g, int nci);
 int cg_conv2d_dgrad(const cg_conv_geom* g, const float* dz, const float* w, int ci0, int nci, float* dx, void* ws,
                     size_t ws_bytes, cg_stream_t stream);
+size_t cg_conv2d_dgrad_workspace_g(const cg_conv_geom* g, const cg_group* group, int nci);
+int cg_conv2d_dgrad_g(const cg_conv_geom* g, const cg_group* group, const float* dz, const float* w, int ci0, int nci,
+                      float* dx, void* ws, size_t ws_bytes, cg_stream_t stream);
 
 /* A/B switch: force the non-pipelined weight-gradient kernel (tuning / regression checks only). */
 int cg_conv2d_wgrad_legacy(int on);
@@ -286,6 +333,38 @@ int cg_gather_rows(const float* src, const int32_t* idx_dev, float* out, int nid
 int cg_loss_match(float* ring_gan, float* ring_council, int n, int pos, const float* council_loss,
                   float* w_out, cg_stream_t stream);
 int cg_ring_push(float* ring, int n, int pos, const float* value, cg_stream_t stream);
+
+/* ---- member-batched forms of the per-member reductions (the reference's member loops, trainer_council.py:328,558,747,
+ *      826,858, as ONE launch): sample / mask blocks of the members follow each other; per-member outputs -------------
+ * cg_lsgan_*_g: nb = samples of ALL members, loss[nmember], gscale[nmember].
+ * cg_focus_*_g: N = samples of ALL members, sums[nmember][3], out[nmember][4], gscale[nmember]; ws nmember x
+ *               cg_focus_workspace().   cg_adam_step_g: the same run of `nmember` pool slices `mstride` elements apart.
+ * cg_ring_push_g / cg_loss_match_g: rings [nmember][n], value / w_out [nmember].
+ * A member's result never depends on which other members share the launch. */
+int cg_lsgan_fwd_g(const float* out, const float* tgt, const float* wt, int nb, int hw, int group, int nmember,
+                   float* loss, int accumulate, cg_stream_t stream);
+int cg_lsgan_bwd_g(const float* out, const float* tgt, const float* wt, const float* gscale, int nb, int hw, int group,
+                   int nmember, float* d_out, cg_stream_t stream);
+int cg_focus_sums_g(const float* mask, int N, int H, int W, int k, int nmember, float center, float eps, float* sums,
+                    void* ws, size_t ws_bytes, cg_stream_t stream);
+int cg_focus_total_g(const float* sums, size_t numel_per_member, int nmember, float w_zo, float w_total, float w_tv,
+                     int use_abs, int use_square, float* out, cg_stream_t stream);
+int cg_focus_bwd_g(const float* mask, const float* sums, const float* gscale, int N, int H, int W, int k, int nmember,
+                   float center, float eps, float w_zo, float w_total, float w_tv, int use_abs, int use_square,
+                   float* d_mask, cg_stream_t stream);
+int cg_adam_step_g(float* p, const float* g, float* m, float* v, size_t n, int nmember, long long mstride, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, cg_stream_t stream);
+int cg_ring_push_g(float* ring, int n, int pos, const float* value, int nmember, cg_stream_t stream);
+int cg_loss_match_g(float* ring_gan, float* ring_council, int n, int pos, const float* council_loss, float* w_out,
+                    int nmember, cg_stream_t stream);
+/* out[i] = idx[i] >= 0 ? src_a[idx[i]] : src_b[-idx[i] - 1] (rows of row_elems floats, a multiple of 4): assembles the
+ * discriminator batches [fake | real] (networks.py:56-82) / [own | colleagues] (trainer_council.py:872-874) of all members */
+int cg_gather_rows2(const float* src_a, const float* src_b, const int32_t* idx_dev, float* out, int nidx,
+                    size_t row_elems, cg_stream_t stream);
+/* generator objective per member (trainer_council.py:447-451,529,588-624): council[m] = council_w * w_match[m] * lc[m],
+ * total[m] = focus[4m] + gan_w * adv[m] + council[m], gcouncil[m] = council_w * w_match[m]; NULL terms are zero */
+int cg_gen_total(const float* focus, const float* adv, const float* lc, const float* w_match, float gan_w,
+                 float council_w, float* total, float* council, float* gcouncil, int nmember, cg_stream_t stream);
 
 
 /* ---- input pipeline tail on the device ---------------------------------------

@@ -564,35 +564,160 @@ def test_conv_epilogue_reports_output_maximum(cga, kind):
         assert float(a.state[1]) == float(r.state[1]) and torch.equal(a.buf, r.buf)
 
 
-@pytest.mark.parametrize("n", [2, 4])
-def test_grouped_split_precision_forward_matches_single_launches(cga, n):
-    """cg_conv2d_fwd_x3_group: the same layer of n council members in one launch == n single-member launches, bit for bit."""
-    import ctypes
-    from ctypes import byref, c_void_p
-    from council_gan_amd import hip, ops
-    lib = hip.load()
-    N, H, W, Cin, Cout, K, stride, pad = 2, 32, 32, 64, 128, 3, 1, 1
-    geom = ops.fwd_geom(N, H, W, Cin, 0, 0, K, K, stride, pad, Cout, ops.ACT["relu"])
-    xs, ws, bs, ys, refs = [], [], [], [], []
-    with torch.no_grad():
+GROUP_CASES = [
+    # name, Cin, C2, Cout, K, stride, pad, up, H, act, split datapath, exact (bit-identical expected)
+    ("first_dis_4x4s2_3to64", 3, 0, 64, 4, 2, 1, 0, 32, "lrelu", True, True),
+    ("first_disc_3x3_3+3to64", 3, 3, 64, 3, 1, 1, 0, 32, "lrelu", True, True),
+    ("fp32_pipe_3x3_64to128", 64, 0, 128, 3, 1, 1, 0, 16, "relu", False, True),
+    ("fp32_pipe_4x4s2_64to128", 64, 0, 128, 4, 2, 1, 0, 16, "lrelu", False, True),
+    ("x3_3x3_64to128", 64, 0, 128, 3, 1, 1, 0, 16, "relu", True, False),
+    ("x3_4x4s2_128to256", 128, 0, 256, 4, 2, 1, 0, 16, "lrelu", True, False),
+    ("x3_up_3x3_128to64", 128, 0, 64, 3, 1, 1, 1, 8, "none", True, False),
+    ("x3_1x1_256to256", 256, 0, 256, 1, 1, 0, 0, 8, "none", True, False),
+    ("head_1x1_256to1", 256, 0, 1, 1, 1, 0, 0, 8, "none", True, False),
+    ("head_1x1_64to12_tanh", 64, 0, 12, 1, 1, 0, 0, 16, "tanh", True, False),
+]
+
+
+@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("case", GROUP_CASES, ids=[c[0] for c in GROUP_CASES])
+def test_member_batched_conv_matches_single_member_launches(cga, case, n):
+    """The same layer of n council members as ONE launch (ops.members(n): batched activations, parameters at a uniform
+    stride in an optim.ParamPool) against n single-member launches: forward, data gradient, weight and bias gradient.
+    fp32 datapath and first layers: bit for bit.  Split-precision layers: the batched tensor gets ONE power-of-two scale
+    instead of one per member, which may move a lo half in or out of fp16's subnormal range -- 2e-6."""
+    from council_gan_amd import ops
+    from council_gan_amd.optim import ParamPool
+    _, Cin, C2, Cout, K, stride, pad, up, H, act, split, exact = case
+    B = 2
+
+    def build():
+        torch.manual_seed(sum(map(ord, case[0])))
+        convs = [torch.nn.Conv2d(Cin + C2, Cout, K, stride, bias=True) for _ in range(n)]
+        for k, c in enumerate(convs):
+            with torch.no_grad():
+                c.bias.normal_()
+                c.weight.mul_(1.0 + 0.25 * k)
+        opts = [cga.FlatAdam(list(c.parameters()), lr=1e-4) for c in convs]
+        pool = ParamPool(opts)
+        pool.materialize('cuda')
+        return convs, pool, (ops.SplitWeights(pool) if split else None)
+
+    torch.manual_seed(7)
+    x = cl(torch.randn(n * B, Cin, H, H).cuda())
+    x2 = cl(torch.randn(n * B, C2, H, H).cuda()) if C2 else None
+    saved = (ops.X3_FORWARD, ops.X3_BACKWARD, ops.X3_DYNAMIC_INPUT)
+    ops.X3_FORWARD = ops.X3_BACKWARD = ops.X3_DYNAMIC_INPUT = split
+    try:
+        def run(convs, pool, mgr, scope, rows):
+            xi = x[rows].clone().requires_grad_(True)
+            x2i = x2[rows].clone().requires_grad_(True) if C2 else None
+            with ops.members(scope):
+                y = ops.conv2d(xi, convs[0].weight, convs[0].bias, stride, pad, act, x2=x2i, upsample=bool(up), wmgr=mgr)
+            return xi, x2i, y
+
+        convs_g, pool_g, mgr_g = build()
+        xi, x2i, y_g = run(convs_g, pool_g, mgr_g, n, slice(0, n * B))
+        torch.manual_seed(8)
+        gy = cl(torch.randn(y_g.shape).cuda())
+        y_g.backward(gy)
+        dx_g = xi.grad
+        dx2_g = x2i.grad if C2 else None
+
+        convs_s, pool_s, mgr_s = build()
+        ys, dxs, dx2s = [], [], []
         for m in range(n):
-            torch.manual_seed(100 + m)
-            x = cl(torch.randn(N, Cin, H, W).cuda() * (1 + m))
-            w = cl((torch.randn(Cout, Cin, K, K) / np.sqrt(Cin * K * K)).cuda())
-            b = torch.randn(Cout).cuda()
-            xs.append(ops.split_f16_dynamic(x))
-            ws.append(ops.split_f16(w, hip.X3_WSCALE))
-            bs.append(b)
-            ys.append(torch.full((N, Cout, geom.Ho, geom.Wo), float("nan"), device="cuda").contiguous(memory_format=torch.channels_last))
-            ref = torch.empty_like(ys[-1])
-            hip.check(lib.cg_conv2d_fwd_x3(byref(geom), xs[m].hi_ptr(), xs[m].lo, ws[m].hi_ptr(), ws[m].lo, float(ws[m].scale),
-                                           xs[m].scale_ptr(), hip.ptr(b), hip.ptr(ref), None, 0, None, 0, None, -1, None, None,
-                                           hip.stream()), "cg_conv2d_fwd_x3")
-            refs.append(ref)
-        tab = lambda ptrs: (c_void_p * n)(*[p if isinstance(p, c_void_p) else c_void_p(p) for p in ptrs])
-        hip.check(lib.cg_conv2d_fwd_x3_group(n, byref(geom), tab([t.hi_ptr() for t in xs]), xs[0].lo,
-                                             tab([t.hi_ptr() for t in ws]), ws[0].lo, float(ws[0].scale),
-                                             tab([t.scale_ptr() for t in xs]), tab([hip.ptr(b) for b in bs]),
-                                             tab([hip.ptr(y) for y in ys]), -1, hip.stream()), "cg_conv2d_fwd_x3_group")
+            rows = slice(m * B, (m + 1) * B)
+            xi, x2i, y = run(convs_s[m:], pool_s, mgr_s, 1, rows)
+            y.backward(gy[rows])
+            ys.append(y.detach()); dxs.append(xi.grad)
+            if C2:
+                dx2s.append(x2i.grad)
+    finally:
+        ops.X3_FORWARD, ops.X3_BACKWARD, ops.X3_DYNAMIC_INPUT = saved
+
+    def close(a, b, what):
+        if exact:
+            assert torch.equal(a, b), what
+        else:
+            e = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+            assert e < 2e-6, (what, e)
+    close(y_g.detach(), torch.cat(ys), "forward")
+    close(dx_g, torch.cat(dxs), "data gradient")
+    if C2:
+        close(dx2_g, torch.cat(dx2s), "data gradient of the second source")
+    close(pool_g.grad, pool_s.grad, "weight / bias gradients (whole pool)")
+    assert float(pool_g.grad.abs().max()) > 0
+
+
+def test_member_batched_losses_and_adam(cga):
+    """Per-member LSGAN / focus criteria, loss matching and the pooled Adam step under ops.members(n) against the
+    single-member calls, bit for bit."""
+    from council_gan_amd import hip, ops
+    from council_gan_amd.optim import ParamPool
+    lib = hip.load()
+    n, B = 3, 2
+    torch.manual_seed(3)
+    outs = [torch.randn(n * 2 * B, 1, 8, 8).cuda().requires_grad_(True), torch.randn(n * 2 * B, 1, 4, 4).cuda().requires_grad_(True)]
+    tgt = torch.tensor(([0.0] * B + [1.0] * B) * n).cuda()
+    wt = torch.tensor([0.5 + 0.1 * i for i in range(n * 2 * B)]).cuda()
+    up = torch.tensor([1.0, 2.0, 0.5]).cuda()
+    with ops.members(n):
+        l = ops.lsgan_loss(outs, tgt, wt, B)
+    assert tuple(l.shape) == (n,)
+    torch.autograd.backward([l], [up])
     for m in range(n):
-        assert torch.equal(ys[m], refs[m]), m
+        rows = slice(m * 2 * B, (m + 1) * 2 * B)
+        o1 = [o.detach()[rows].clone().requires_grad_(True) for o in outs]
+        l1 = ops.lsgan_loss(o1, tgt[rows].clone(), wt[rows].clone(), B)
+        assert float(l1) == float(l[m]), m
+        (l1 * up[m]).backward()
+        for a, b in zip(o1, outs):
+            assert torch.equal(a.grad, b.grad[rows]), m
+    mask = cl(torch.rand(n * B, 3, 16, 16).cuda()).requires_grad_(True)
+    with ops.members(n):
+        ft, parts = ops.focus_loss(mask, 0.5, 0.01, 1.0, 3.0, 0.5, False, True)
+    torch.autograd.backward([ft], [up])
+    for m in range(n):
+        rows = slice(m * B, (m + 1) * B)
+        mk = mask.detach()[rows].clone().requires_grad_(True)
+        f1, p1 = ops.focus_loss(mk, 0.5, 0.01, 1.0, 3.0, 0.5, False, True)
+        assert float(f1) == float(ft[m]) and torch.equal(p1, parts[m]), m
+        (f1 * up[m]).backward()
+        assert torch.equal(mk.grad, mask.grad[rows]), m
+    # pooled Adam: one launch for every member == per-member steps
+    def build():
+        torch.manual_seed(5)
+        ps = [[torch.nn.Parameter(torch.randn(40, 8, 3, 3)), torch.nn.Parameter(torch.randn(40))] for _ in range(n)]
+        pool = ParamPool([cga.FlatAdam(p, lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-4) for p in ps])
+        pool.materialize('cuda')
+        torch.manual_seed(6)
+        pool.grad.copy_(torch.randn(pool.grad.shape).cuda())
+        return ps, pool
+    ps_a, pool_a = build()
+    ps_b, pool_b = build()
+    for p in ps_a[0]:
+        p._cg_grad._cg_touched = True           # member-batched launches flag the lead member only
+    for mem in ps_b:
+        for p in mem:
+            p._cg_grad._cg_touched = True
+    for _ in range(2):
+        pool_a.step(0, n, lockstep=True)
+        for o in pool_b.opts:
+            o.step()
+    assert torch.equal(pool_a.data, pool_b.data) and torch.equal(pool_a.m, pool_b.m) and torch.equal(pool_a.v, pool_b.v)
+    assert [o._steps for o in pool_a.opts] == [o._steps for o in pool_b.opts] == [[2, 2]] * n
+    # rings / loss matching / objective assembly
+    ring_g, ring_c = torch.ones(n * 5).cuda(), torch.ones(n * 5).cuda()
+    adv, lc, w = torch.tensor([1.0, 2.0, 3.0]).cuda(), torch.tensor([4.0, 5.0, 6.0]).cuda(), torch.zeros(n).cuda()
+    hip.check(lib.cg_ring_push_g(hip.ptr(ring_g), 5, 7, hip.ptr(adv), n, hip.stream()), "ring")
+    hip.check(lib.cg_loss_match_g(hip.ptr(ring_g), hip.ptr(ring_c), 5, 7, hip.ptr(lc), hip.ptr(w), n, hip.stream()), "match")
+    want_w = [((4 + a) / 5) / ((4 + c) / 5) for a, c in zip((1.0, 2.0, 3.0), (4.0, 5.0, 6.0))]
+    assert np.allclose(w.cpu().numpy(), want_w, rtol=1e-6)
+    assert float(ring_g[5 + 7 % 5]) == 2.0 and float(ring_c[10 + 7 % 5]) == 6.0
+    total, council, gc = ops.gen_total(ft.detach(), adv, lc, w, 1.0, 6.0, n)
+    assert np.allclose(council.cpu().numpy(), [6.0 * a * b for a, b in zip(want_w, (4.0, 5.0, 6.0))], rtol=1e-6)
+    assert np.allclose(total.cpu().numpy(), (ft.detach() + adv + council).cpu().numpy(), rtol=1e-6)
+    assert np.allclose(gc.cpu().numpy(), [6.0 * a for a in want_w], rtol=1e-6)
+    t = ops.take_rows(mask.detach(), outs[0].detach().view(n * 2 * B, 64)[:, :0] if False else None, [3, 0, 5])
+    assert torch.equal(t, mask.detach()[[3, 0, 5]])

@@ -95,17 +95,14 @@ def test_sharded_trainer_matches_single_process(world, council):
     for it in range(2):
         for got, want in zip(res[0][1][it], ref[1][it]):
             for g, w in zip(got, want):
-                if dp == 1:
-                    assert g == w, (it, got, want)          # member sharding moves whole members: bit-identical
-                else:
-                    assert abs(g - w) <= 2e-4 * max(abs(w), 1e-3), (it, got, want)    # different summation order
+                # member sharding moves whole members, but a rank's members run as ONE member-batched launch: the tile shapes
+                # (summation order of the fp64 norm partials) and the per-tensor power-of-two scale of a batched split
+                # tensor depend on how many members share the launch; data parallelism also changes the batch reductions
+                assert abs(g - w) <= 2e-4 * max(abs(w), 1e-3), (it, got, want)
     wsum = {}
     for r in res:
         for m, v in r[2].items():
             wsum.setdefault(m, []).append(v)
     for m, vs in wsum.items():
         assert all(v == vs[0] for v in vs), "replicas of member %d diverged" % m
-        if dp == 1:
-            assert vs[0] == ref[2][m]
-        else:
-            assert abs(vs[0] - ref[2][m]) <= 1e-3 * max(abs(ref[2][m]), 1.0)
+        assert abs(vs[0] - ref[2][m]) <= 1e-3 * max(abs(ref[2][m]), 1.0)
