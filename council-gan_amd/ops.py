@@ -555,7 +555,7 @@ class SplitWeights:
     """{hi, lo} fp16 planes of ALL parameters of one optimizer (optim.FlatAdam) or of one pool of member optimizers
     (optim.ParamPool), re-split lazily -- one kernel over the flat storage -- whenever the owner's `version` moved (a step,
     a checkpoint load).  The power-of-two scale is chosen ON THE DEVICE from the storage's largest magnitude, capped at
-    hip.X3_WSCALE = 2^10: ordinary weights (|w| <= 1/16) get exactly the static scale of round 1, larger ones (a loaded
+    hip.X3_WSCALE = 2^10: ordinary weights (|w| < 8) get exactly the static scale of round 1, larger ones (a loaded
     checkpoint) the smaller scale that keeps their hi halves finite; consumers read it from `state` (scale_ptr).
     `get(weight)` returns the SplitTensor view of one conv weight, or None for tensors the owner does not hold.
     `dgrad_weights(...)` caches the re-laid-out, split data-gradient weights of a layer per weight version."""
@@ -641,7 +641,7 @@ def split_f16(x, scale=1.0):
 
 def split_f16_dynamic(x, amax=None):
     """fp32 tensor of ARBITRARY magnitude (a gradient, an un-normalised activation) -> SplitTensor whose planes hold
-    scale*x, scale = the power of two that puts max|x| into [32, 64), chosen on the device (no host sync)."""
+    scale*x, scale = the power of two that puts max|x| into [4096, 8192), chosen on the device (no host sync)."""
     x = nhwc(x) if x.dim() == 4 else x.contiguous()
     buf = torch.empty(2 * x.numel(), dtype=torch.float16, device=x.device)
     if amax is not None:            # (state, nslots) left behind by the kernel that produced x

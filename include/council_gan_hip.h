@@ -130,7 +130,7 @@ int cg_conv2d_fwd_g(const cg_conv_geom* g, const cg_group* group, const float* x
 int cg_conv2d_fwd_amax(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias, float* y,
                        float* amax_state, int* amax_nslots, cg_stream_t stream);
 /* Tensors of arbitrary magnitude (gradients, un-normalised activations) are split with a per-tensor power-of-two scale
- * chosen ON THE DEVICE: state[0] <- max|x|, state[1] <- scale = 2^(5 - floor(log2 max|x|)) (scaled peak in [32, 64));
+ * chosen ON THE DEVICE: state[0] <- max|x|, state[1] <- scale = 2^(12 - floor(log2 max|x|)) (scaled peak in [4096, 8192): three binades below fp16's maximum);
  * state[2 .. CG_SPLIT_STATE_FLOATS) is scratch (per-block maxima).  The halves hold scale*x;
  * consumers take `state + 1` as x_scale_dev / dz_scale_dev and undo the scale in their epilogue.  No host sync. */
 #define CG_SPLIT_STATE_FLOATS 1026
@@ -138,8 +138,8 @@ int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, f
                          cg_stream_t stream);   /* nslots > 0: a producer kernel already left that many per-block maxima
                                                    in state[2..] (cg_instnorm_bwd, cg_conv2d_fwd_amax, cg_conv2d_fwd_x3);
                                                    0: measure here */
-/* The same with the scale capped: scale = min(max_scale, 2^(5 - floor(log2 max|x|))), max_scale a power of two (0 = no
- * cap).  Used for the WEIGHTS of an optimizer pool with max_scale = CG_X3_WSCALE: ordinary weights (|w| <= 1/16) keep
+/* The same with the scale capped: scale = min(max_scale, 2^(12 - floor(log2 max|x|))), max_scale a power of two (0 = no
+ * cap).  Used for the WEIGHTS of an optimizer pool with max_scale = CG_X3_WSCALE: ordinary weights (|w| < 8) keep
  * the static 2^10, larger ones (a loaded checkpoint) get the smaller scale that keeps their hi halves finite. */
 int cg_split_f16_dynamic_capped(const float* x, void* out, size_t n, size_t lo_elems, float* state, int nslots,
                                 float max_scale, cg_stream_t stream);
