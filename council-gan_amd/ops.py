@@ -216,7 +216,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.xsplit = xsplit if (xsplit is not None and wsplit is not None) else None     # reused by the x3 weight gradient
         ctx.g, ctx.meta = g, (KH, KW, stride, pad, act, int(up), bias is not None)
         ctx.wgrad_buf, ctx.bgrad_buf = wgrad_buf, bgrad_buf
-        ctx.grp, ctx.weight, ctx.wmgr = grp, wparam, wmgr
+        ctx.grp, ctx.weight, ctx.wmgr, ctx.nm = grp, wparam, wmgr, _G.n      # backward may run outside the members() scope
         return y
 
     @staticmethod
@@ -231,7 +231,9 @@ class _Conv2d(torch.autograd.Function):
         # split-precision backward: dz gets a device-side power-of-two scale once, for both gradients
         need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
         need_dw = ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3])
-        x3_dgrad = X3_BACKWARD and need_dx and g.Cout % 32 == 0 and g.stride <= 2
+        # (a member-batched launch reads the prepared data-gradient weights of a pool: plain tensors / linears stay fp32)
+        x3_dgrad = X3_BACKWARD and need_dx and g.Cout % 32 == 0 and g.stride <= 2 and \
+            (grp is None or (ctx.wmgr is not None and ctx.weight is not None))
         x3_wgrad = X3_BACKWARD and need_dw and ctx.xsplit is not None and bool(lib.cg_conv2d_wgrad_x3_ok_g(byref(g), grp))
         fp32_needed = (need_dx and not x3_dgrad) or (need_dw and not x3_wgrad)
         dzs = None
@@ -271,7 +273,7 @@ class _Conv2d(torch.autograd.Function):
         # data gradients: split-precision kernel when the layer qualifies (dz gets a device-side power-of-two scale)
         def dgrad(ci0, nci):
             if x3_dgrad:
-                return conv_dgrad_x3(g, dzs, w, ci0, nci, grp=grp, weight=ctx.weight, wmgr=ctx.wmgr)
+                return conv_dgrad_x3(g, dzs, w, ci0, nci, grp=grp, weight=ctx.weight, wmgr=ctx.wmgr, nm=ctx.nm)
             return conv_dgrad(g, dz, w, ci0, nci, grp=grp)
         if ctx.needs_input_grad[0]:
             dx = dgrad(0, x.shape[1])
@@ -663,7 +665,7 @@ def act_bwd_split(dy, y, act, want_fp32):
     return dz, SplitTensor(buf, dy.shape, state=state)
 
 
-def conv_dgrad_x3(g, dz, w, ci0, nci, grp=None, weight=None, wmgr=None):
+def conv_dgrad_x3(g, dz, w, ci0, nci, grp=None, weight=None, wmgr=None, nm=1):
     """conv_dgrad on the split-precision kernel: dz is split with its device-side scale; needs Cout % 32 == 0.  The weights
     are re-laid-out and split per launch into the workspace -- or, for a parameter of a SplitWeights-managed optimizer
     (`weight`, `wmgr`), once per weight version (SplitWeights.dgrad_weights)."""
@@ -671,7 +673,7 @@ def conv_dgrad_x3(g, dz, w, ci0, nci, grp=None, weight=None, wmgr=None):
     N, H, W, up = g.N, g.H, g.W, g.up
     dzs = dz if isinstance(dz, SplitTensor) else split_f16_dynamic(dz)
     dxl = torch.empty((N, nci, H << up, W << up), dtype=torch.float32, device=dzs.buf.device, memory_format=CL)
-    wt = wmgr.dgrad_weights(weight, w, g, ci0, nci, grp, _G.n) if (wmgr is not None and weight is not None) else None
+    wt = wmgr.dgrad_weights(weight, w, g, ci0, nci, grp, nm) if (wmgr is not None and weight is not None) else None
     if wt is not None:
         check(lib.cg_conv2d_dgrad_x3_run(byref(g), grp, dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), ptr(wt), 1.0, wmgr.scale_ptr(),
                                          ci0, nci, ptr(dxl), stream()), "cg_conv2d_dgrad_x3_run")

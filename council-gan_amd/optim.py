@@ -239,13 +239,13 @@ class ParamPool:
         n = len(self.opts) - k0 if n is None else n
         opts = self.opts[k0:k0 + n]
         lead = opts[0]
+        if lockstep:
+            for o in opts[1:]:
+                for p, q in zip(o._params, lead._params):
+                    p._cg_grad._cg_touched = q._cg_grad._cg_touched
         same = lockstep and all(o._steps == lead._steps and o.param_groups[0]['lr'] == lead.param_groups[0]['lr']
                                 for o in opts[1:])
         if not same or n == 1:
-            if lockstep:
-                for o in opts[1:]:
-                    for p, q in zip(o._params, lead._params):
-                        p._cg_grad._cg_touched = q._cg_grad._cg_touched
             for o in opts:
                 o.step()
             return

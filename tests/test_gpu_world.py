@@ -34,53 +34,66 @@ def _cfg(council):
     return cfg
 
 
-def _worker(rank, world, port, council, q):
+def _worker(rank, world, port, council, q, backend="gloo"):
     import council_gan_amd as cga
     from oracle import council_oracle as O
+    dev = 'cuda:0'
     if world > 1:
+        # gloo: every rank shares cuda:0 (one-GPU box); nccl (= RCCL): one GPU per rank
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          LOCAL_RANK="0")
-        cga.init_distributed("gloo")
+                          LOCAL_RANK=str(rank) if backend == "nccl" else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cga.init_distributed(backend)
+        if backend == "nccl":
+            dev = 'cuda:%d' % rank
     try:
-        cfg = _cfg(council)
-        O.seed_all(3)
-        tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
-        tr.cuda('cuda:0')
-        x_a, x_b = O.synthetic_batch(4, 64)
-        x_a, x_b = x_a.cuda(), x_b.cuda()
-        rows = []
-        for it in range(2):
-            O.seed_all(20 + it)
-            tr.dis_update(x_a, x_b, cfg)
-            tr.dis_council_update(x_a, x_b, cfg)
-            tr.gen_update(x_a, x_b, cfg, 60000 + it)
-            row = []
-            for name in ('loss_dis_total_s', 'loss_dis_council_total_s', 'loss_gen_total_s', 'loss_gen_adv_a2b_s',
-                         'council_loss_ab_s'):
-                vals = [float(v) for v in getattr(tr, name)]
-                row.append(tr.shard.gather_scalars(vals))
-            rows.append(row)
-        # one weight tensor with a real gradient per local member, replicas must agree bit for bit
-        wsum = {m: float(tr.gen_a2b_s[m].state_dict()['dec.model.0.model.0.model.0.conv.weight'].double().sum())
-                for m in tr.shard.local}
-        q.put((rank, rows, wsum, tr.shard.dp))
+        try:
+            cfg = _cfg(council)
+            O.seed_all(3)
+            tr = cga.Council_Trainer(copy.deepcopy(cfg), dev)
+            tr.cuda(dev)
+            x_a, x_b = O.synthetic_batch(4, 64)
+            x_a, x_b = x_a.to(dev), x_b.to(dev)
+            rows = []
+            for it in range(2):
+                O.seed_all(20 + it)
+                tr.dis_update(x_a, x_b, cfg)
+                tr.dis_council_update(x_a, x_b, cfg)
+                tr.gen_update(x_a, x_b, cfg, 60000 + it)
+                row = []
+                for name in ('loss_dis_total_s', 'loss_dis_council_total_s', 'loss_gen_total_s', 'loss_gen_adv_a2b_s',
+                             'council_loss_ab_s'):
+                    vals = [float(v) for v in getattr(tr, name)]
+                    row.append(tr.shard.gather_scalars(vals))
+                rows.append(row)
+            # one weight tensor with a real gradient per local member, replicas must agree bit for bit
+            wsum = {m: float(tr.gen_a2b_s[m].state_dict()['dec.model.0.model.0.model.0.conv.weight'].double().sum())
+                    for m in tr.shard.local}
+            q.put((rank, rows, wsum, tr.shard.dp))
+        except Exception:       # report instead of leaving the parent to wait for its queue timeout
+            import traceback
+            q.put((rank, "error", traceback.format_exc(), 0))
+            raise
     finally:
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
 
 
-def _run(world, council):
+def _run(world, council, backend="gloo"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, council, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, council, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=500) for _ in procs)
+    res = [q.get(timeout=300) for _ in procs]
+    errs = [r for r in res if r[1] == "error"]
     for p in procs:
-        p.join(120)
+        p.join(60)
+    assert not errs, errs[0][2]
+    for p in procs:
         assert p.exitcode == 0
+    res = sorted(res)
     return res
 
 
@@ -106,3 +119,18 @@ def test_sharded_trainer_matches_single_process(world, council):
     for m, vs in wsum.items():
         assert all(v == vs[0] for v in vs), "replicas of member %d diverged" % m
         assert abs(vs[0] - ref[2][m]) <= 1e-3 * max(abs(ref[2][m]), 1.0)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL transport needs two GPUs (this box has one)")
+@pytest.mark.parametrize("world,council", [(2, 2), (2, 4)])
+def test_sharded_trainer_over_rccl(world, council):
+    """The shipped transport: backend "nccl" = RCCL over xGMI, one GPU per rank -- runs wherever the box has >= 2 GPUs
+    (the driver's multi-GPU node); same criteria as the gloo run above."""
+    ref = _run(1, council)[0]
+    res = _run(world, council, backend="nccl")
+    for r in res:
+        assert r[1] == res[0][1], "gathered losses differ between ranks"
+    for it in range(2):
+        for got, want in zip(res[0][1][it], ref[1][it]):
+            for g, w in zip(got, want):
+                assert abs(g - w) <= 2e-4 * max(abs(w), 1e-3), (it, got, want)
