@@ -222,8 +222,9 @@ def main():
                                          if trainer._split_fwd else "fp32 MFMA everywhere"),
                    "members_per_launch": (len(trainer._groups[1][0]) if trainer._groups else 1),
                    "execution": ("member-batched: the local members' same layer runs as ONE launch (ops.members, "
-                                 "optim.ParamPool); CG_GROUP=1 walks the members one by one on %d HIP stream(s)"
-                                 % (len(trainer._streams) or 1))},
+                                 "optim.ParamPool); discriminator / council-discriminator updates on two side streams: %s; "
+                                 "weight gradients on a companion stream: %s"
+                                 % ("on" if trainer._overlap else "off", "on" if cga.ops.WGRAD_STREAM else "off"))},
     }
 
     if rank == 0 and world == 1:
@@ -246,6 +247,8 @@ def main():
             # one more iteration with HIP events around every MFMA conv launch (on the launch stream); a failure of this
             # extra leg must not cost the headline number measured above
             streams, trainer._streams = trainer._streams, []     # serialised: a launch's events see only that launch
+            overlap, trainer._overlap = trainer._overlap, False  # (no side streams, no companion weight-gradient stream)
+            wstream, cga.ops.WGRAD_STREAM = cga.ops.WGRAD_STREAM, False
             try:
                 cga.hip.prof_enable(True)
                 step(args.warmup + args.steps)
@@ -255,7 +258,7 @@ def main():
                 roof["profile_error"] = "%s: %s" % (type(e).__name__, e)
             finally:
                 cga.hip.prof_enable(False)
-                trainer._streams = streams
+                trainer._streams, trainer._overlap, cga.ops.WGRAD_STREAM = streams, overlap, wstream
         if prof:
             if args.shape_report:
                 open(args.shape_report, "w").write(cga.hip.prof_report())

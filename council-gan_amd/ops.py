@@ -12,6 +12,7 @@ and autograd receives None for that input; otherwise the gradient is returned no
 """
 import contextlib
 import ctypes
+import os
 from ctypes import byref, c_void_p
 
 import torch
@@ -248,7 +249,6 @@ class _Conv2d(torch.autograd.Function):
             if x3_dgrad or x3_wgrad:
                 dzs = split_f16_dynamic(dz, amax)
         if need_dw:
-            ws = workspace(lib.cg_conv2d_wgrad_workspace_g(byref(g), grp))
             if ctx.wgrad_buf is not None:
                 # accumulate straight into the optimizer's flat gradient buffer (optim.py); grouped: every member's slice
                 dw_t, acc = ctx.wgrad_buf, 1
@@ -262,14 +262,27 @@ class _Conv2d(torch.autograd.Function):
                 dw_t, acc = torch.empty_like(w), 0
                 db_t = torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if has_bias else None
                 dw, db = dw_t, db_t
-            if x3_wgrad:
-                xs = ctx.xsplit
-                check(lib.cg_conv2d_wgrad_x3_g(byref(g), grp, xs.hi_ptr(), xs.lo, xs.scale_ptr(), dzs.hi_ptr(), dzs.lo,
-                                               dzs.scale_ptr(), ptr(dw_t), ptr(db_t), acc, ptr(ws), ws.numel(), stream()),
-                      "cg_conv2d_wgrad_x3")
-            else:
-                check(lib.cg_conv2d_wgrad_g(byref(g), grp, ptr(x), ptr(x2), ptr(dz), ptr(dw_t), ptr(db_t), acc, ptr(ws),
-                                            ws.numel(), stream()), "cg_conv2d_wgrad")
+            side = _companion() if acc else None      # (gradients returned to autograd stay on the compute stream)
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record()                           # dz / its split form and the zeroed gradient buffers are ready
+                side.wait_event(ev)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                ws = workspace(lib.cg_conv2d_wgrad_workspace_g(byref(g), grp))
+                if x3_wgrad:
+                    xs = ctx.xsplit
+                    check(lib.cg_conv2d_wgrad_x3_g(byref(g), grp, xs.hi_ptr(), xs.lo, xs.scale_ptr(), dzs.hi_ptr(), dzs.lo,
+                                                   dzs.scale_ptr(), ptr(dw_t), ptr(db_t), acc, ptr(ws), ws.numel(), stream()),
+                          "cg_conv2d_wgrad_x3")
+                    used = (xs.buf, xs.state, dzs.buf, dzs.state)
+                else:
+                    check(lib.cg_conv2d_wgrad_g(byref(g), grp, ptr(x), ptr(x2), ptr(dz), ptr(dw_t), ptr(db_t), acc, ptr(ws),
+                                                ws.numel(), stream()), "cg_conv2d_wgrad")
+                    used = (x, x2, dz)
+            if side is not None:                      # the allocator must not hand these blocks out before the companion
+                for t in used:                        # stream has read them
+                    if t is not None:
+                        t.record_stream(side)
         # data gradients: split-precision kernel when the layer qualifies (dz gets a device-side power-of-two scale)
         def dgrad(ci0, nci):
             if x3_dgrad:
@@ -281,6 +294,34 @@ class _Conv2d(torch.autograd.Function):
         if x2 is not None and ctx.needs_input_grad[1]:
             dx2 = dgrad(x.shape[1], x2.shape[1])
         return (dx, dx2, dw, db) + (None,) * 13
+
+
+# Weight gradients leave the chain of dependent backward kernels: nothing downstream of a layer's backward needs its dW
+# before the optimizer step.  They are therefore launched on a COMPANION stream of the stream the backward runs on (one
+# per compute stream), behind an event that marks "dz is ready", and the compute stream goes straight on with the data
+# gradient: the MFMA-bound weight-gradient kernels then share the GPU with the HBM-bound passes of the chain (norm /
+# activation backward, splits) instead of queueing between them.  wgrad_join() -- called by the trainer before the
+# optimizer step -- makes the compute stream wait for its companion.  CG_WGRAD_STREAM=0 keeps everything in line.
+WGRAD_STREAM = os.environ.get("CG_WGRAD_STREAM", "1") != "0"
+_companions = {}
+
+
+def _companion():
+    """Companion stream of the current stream (created on first use), or None when the feature is off."""
+    if not WGRAD_STREAM:
+        return None
+    key = hip._stream_handle()
+    st = _companions.get(key)
+    if st is None:
+        st = _companions[key] = torch.cuda.Stream()
+    return st
+
+
+def wgrad_join():
+    """The current stream continues after every weight gradient launched from it so far (no host wait)."""
+    st = _companions.get(hip._stream_handle())
+    if st is not None:
+        torch.cuda.current_stream().wait_stream(st)
 
 
 X3_FORWARD = True     # module switches (Council_Trainer sets them from the config): split-precision forward convolutions,

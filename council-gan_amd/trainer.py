@@ -395,7 +395,8 @@ class Council_Trainer(nn.Module):
                     xr = self._rep(x[d], len(grp))
                     if less != 0 and self.council_size > 1:
                         self._rep(x[d], 2 * len(grp))
-                    self._content(d, grp, xr, need_grad=False)
+                    with ops.members(len(grp)):
+                        self._content(d, grp, xr, need_grad=False)
             if self._split_fwd:
                 self._pools['gen'].split.refresh()
             ev = torch.cuda.Event()
@@ -525,6 +526,7 @@ class Council_Trainer(nn.Module):
                             t = l.detach()[m] if w == 1.0 else l.detach()[m] * w
                             tot = t if tot is None else tot + t
                         self.loss_dis_total_s[i] = tot
+                    ops.wgrad_join()
                     self._sync_grads(pool, k0, g)
                     pool.step(k0, g, lockstep=g > 1)
             self._join()
@@ -620,6 +622,7 @@ class Council_Trainer(nn.Module):
                         for l in losses:
                             tot = l.detach()[m] if tot is None else tot + l.detach()[m]
                         self.loss_dis_council_total_s[i] = tot
+                    ops.wgrad_join()
                     self._sync_grads(pool, k0, g)
                     pool.step(k0, g, lockstep=g > 1)
             self._join()
@@ -762,6 +765,7 @@ class Council_Trainer(nn.Module):
                             tot = t[m] if tot is None else tot + t[m]
                         self.loss_gen_total_s[i] = tot
                     torch.autograd.backward(roots, ups)
+                    ops.wgrad_join()
                     self._sync_grads(pool, k0, g)
                     pool.step(k0, g, lockstep=g > 1)
         finally:

@@ -137,6 +137,7 @@ def test_conv2d_accumulates_into_flat_grad(cga):
     assert w.grad is None and b.grad is None
     wc = w.detach().cpu().double().requires_grad_(True)
     ref_w = torch.autograd.grad(F.conv2d(x.cpu().double(), wc, None, padding=1).sum(), wc)[0]
+    cga.ops.wgrad_join()          # weight gradients run on a companion stream of the backward's stream (ops._companion)
     assert rel(w._cg_grad - 1, ref_w) < TOL
     assert rel(b._cg_grad - 1, torch.full((64,), 2 * 8 * 8.0)) < TOL
     assert w._cg_grad._cg_touched and b._cg_grad._cg_touched
@@ -642,6 +643,7 @@ def test_member_batched_conv_matches_single_member_launches(cga, case, n):
         else:
             e = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
             assert e < 2e-6, (what, e)
+    ops.wgrad_join()              # weight gradients run on a companion stream of the backward's stream
     close(y_g.detach(), torch.cat(ys), "forward")
     close(dx_g, torch.cat(dxs), "data gradient")
     if C2:
