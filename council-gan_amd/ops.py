@@ -301,8 +301,10 @@ class _Conv2d(torch.autograd.Function):
 # per compute stream), behind an event that marks "dz is ready", and the compute stream goes straight on with the data
 # gradient: the MFMA-bound weight-gradient kernels then share the GPU with the HBM-bound passes of the chain (norm /
 # activation backward, splits) instead of queueing between them.  wgrad_join() -- called by the trainer before the
-# optimizer step -- makes the compute stream wait for its companion.  CG_WGRAD_STREAM=0 keeps everything in line.
-WGRAD_STREAM = os.environ.get("CG_WGRAD_STREAM", "1") != "0"
+# optimizer step -- makes the compute stream wait for its companion.  Measured on the member-batched step: 73.5 ms with it
+# against 71.7 ms without (the weight-gradient kernels are MFMA-bound like the data-gradient kernels they then compete with,
+# and the batched elementwise passes are too short to hide them) -- so it is OFF unless CG_WGRAD_STREAM=1.
+WGRAD_STREAM = os.environ.get("CG_WGRAD_STREAM", "0") == "1"
 _companions = {}
 
 
