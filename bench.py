@@ -40,7 +40,7 @@ F16X3_PEAK_TFLOPS = 2500.0 / 3    # split-precision kernels: dense fp16 MFMA pea
 
 
 def kernel_peak(name):
-    return F16X3_PEAK_TFLOPS if "_x3_" in name else FP32_MFMA_PEAK_TFLOPS
+    return F16X3_PEAK_TFLOPS if "_x3" in name else FP32_MFMA_PEAK_TFLOPS
 
 # per-forward GFLOP at sigma = B*(H/128)^2 = 1 (hooks on every Conv2d/Linear)
 _S, _A, _D, _P, _Q, _c1, _p1, _q1 = 3.127, 14.535, 19.621, 1.038, 4.336, 0.308, 0.031, 0.142

@@ -1160,7 +1160,8 @@ int tile_id(int bm, int bn) {
     if (bm == 64 && bn == 128) return 3;
     if (bm == 64 && bn == 64) return 4;
     if (bm == 32 && bn == 128) return 5;
-    if (bm == 256) return 6;
+    if (bm == 256 && bn == 128) return 6;
+    if (bm == 256 && bn == 256) return 8;
     return 7;  // 128x32 / 64x64-class leftovers
 }
 struct ProfScope {
@@ -1176,10 +1177,11 @@ struct ProfScope {
         if (g)
             snprintf(rec.key, sizeof(rec.key), "f%d %3dx%-3d N%-2d %3dx%-3d C%-3d->%-3d T%-2d s%d u%d out%dx%d x%d", family, bm,
                      bn, g->N, g->H, g->W, g->C1 + g->C2, g->Cout, g->T, g->stride, g->up, g->Ho, g->Wo, ncls);
-        rec.slot = family * 16 + tile_id(bm, bn) * 2 + (fast ? 1 : 0);
+        rec.slot = family * 20 + tile_id(bm, bn) * 2 + (fast ? 1 : 0);
         rec.flops = flops;
-        static const char* const fam[6] = {"conv_fwd_kernel", "conv_wgrad_kernel", "conv_fwd_pipe_kernel",
-                                           "conv_wgrad_pipe_kernel", "conv_fwd_x3_kernel", "conv_wgrad_x3_kernel"};
+        static const char* const fam[8] = {"conv_fwd_kernel",    "conv_wgrad_kernel",    "conv_fwd_pipe_kernel",
+                                           "conv_wgrad_pipe_kernel", "conv_fwd_x3_kernel", "conv_wgrad_x3_kernel",
+                                           "conv_fwd_x3w_kernel", "conv_wgrad_x3t_kernel"};
         snprintf(prof_names[rec.slot], sizeof(prof_names[0]), "%s<%d,%d,%s>", fam[family], bm, bn, fast ? "fast" : "generic");
         (void)hipEventCreate(&rec.e0);
         (void)hipEventCreate(&rec.e1);
@@ -1776,7 +1778,7 @@ int launch_wgrad_x3t(const cg_conv_geom* g, const WgradPlan& p, const void* xs, 
                      hipStream_t st, int nmember) {
     dim3 grid(p.tiles_m * p.tiles_n, nmember, p.splits), block((BM / WM) * (BN / WN) * 64);
     const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)g->N * g->Ho * g->Wo * g->Cout * 2;
-    ProfScope prof(5, BM, BN, true, 2.0 * (double)M * nmember * (double)g->Cout * (double)K, st, g, nmember);
+    ProfScope prof(7, BM, BN, true, 2.0 * (double)M * nmember * (double)g->Cout * (double)K, st, g, nmember);
     hipLaunchKernelGGL((conv_wgrad_x3t_kernel<BM, BN, WM, WN>), grid, block, 0, st, *g, xs, (unsigned)x3_span(x_lo, x_plane),
                        x_scale, dzs, (unsigned)x3_span(dz_lo, dz_plane), dz_scale, out, M, K, p.tiles_n, p.slices_per_split,
                        want_bias, ilog2_exact(g->Ho * g->Wo), ilog2_exact(g->Wo));

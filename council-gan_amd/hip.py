@@ -205,7 +205,7 @@ def workspace(nbytes, slot=0):
     return buf
 
 
-PROF_SLOTS = 96
+PROF_SLOTS = 160
 
 
 def prof_enable(on):

@@ -308,9 +308,9 @@ int cg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
 /* ---- opt-in per-kernel timing (bench.py's roofline leg; off by default, no cost when off) -------
  * While enabled, every MFMA conv launch (forward/dgrad kernel and wgrad kernel) is bracketed by
  * HIP events recorded on the launch stream.  cg_prof_collect() synchronises them and returns, per
- * kernel slot (slot = kernel family * 16 + tile shape * 2 + fast-path flag; see cg_prof_slot_name),
+ * kernel slot (slot = kernel family * 20 + tile shape * 2 + fast-path flag; see cg_prof_slot_name),
  * launch count, total milliseconds and total algorithmic FLOPs (2*M*N*K of each launch). */
-#define CG_PROF_SLOTS 96
+#define CG_PROF_SLOTS 160
 int cg_prof_enable(int on);
 int cg_prof_collect(int64_t* counts, double* ms, double* flops);
 const char* cg_prof_slot_name(int slot);
