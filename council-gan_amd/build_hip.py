@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("conv_gemm.hip", "norm.hip", "elementwise.hip")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("conv_gemm.hip", "norm.hip", "elementwise.hip", "collective.hip")]
 DEPS = SRC + [os.path.join(HERE, "csrc", "cg_common.h"), os.path.join(HERE, "csrc", "conv_x3.inc"), os.path.join(HERE, "..", "include", "council_gan_hip.h")]
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libcouncilgan_hip.so")
@@ -31,7 +31,7 @@ def build(force=False, verbose=True):
     if not force and os.path.exists(OUT) and os.path.exists(STAMP) and open(STAMP).read() == dig:
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + SRC + ["-o", OUT]
+    cmd = [hipcc] + FLAGS + SRC + ["-ldl", "-o", OUT]
     if verbose:
         print("[build_hip]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -128,6 +128,12 @@ _SIGS = {
     "cg_prof_collect": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     "cg_prof_slot_name": (c_char_p, [c_int]),
     "cg_prof_report": (c_char_p, []),
+    "cg_comm_unique_id": (c_int, [_P]),
+    "cg_comm_create": (c_int, [_P, c_int, c_int, POINTER(c_void_p)]),
+    "cg_comm_destroy": (c_int, [_P]),
+    "cg_comm_info": (c_int, [_P, POINTER(c_int), POINTER(c_int)]),
+    "cg_allgather_images": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "cg_allreduce_sum": (c_int, [_P, _P, c_size_t, _P]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -229,3 +235,51 @@ def prof_collect():
 def prof_report():
     """Per-layer-shape text table of the last prof_collect()."""
     return load().cg_prof_report().decode()
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """The 128-byte id the first rank of a group draws and hands to the others (cg_comm_unique_id)."""
+    buf = (ctypes.c_ubyte * COMM_ID_BYTES)()
+    check(load().cg_comm_unique_id(buf), "cg_comm_unique_id")
+    return bytes(buf)
+
+
+class Comm:
+    """One RCCL communicator of the C-ABI (include/council_gan_hip.h: cg_comm_*): this rank's membership in one process
+    group.  Creation is collective over the group; the calls enqueue on the current stream."""
+
+    def __init__(self, uid, rank, nranks):
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError("communicator id must be %d bytes" % COMM_ID_BYTES)
+        self._h = c_void_p()
+        self.rank, self.nranks = rank, nranks
+        buf = (ctypes.c_ubyte * COMM_ID_BYTES).from_buffer_copy(uid)
+        check(load().cg_comm_create(buf, rank, nranks, ctypes.byref(self._h)), "cg_comm_create")
+
+    def all_gather(self, recv, send):
+        """recv (flat, nranks x send.numel() fp32) <- every rank's send (contiguous fp32), on the current stream."""
+        if recv.numel() != self.nranks * send.numel() or not (send.is_contiguous() and recv.is_contiguous()):
+            raise HipError("all_gather: recv must be a contiguous nranks x send buffer")
+        if send.dtype != torch.float32 or recv.dtype != torch.float32:
+            raise HipError("all_gather: fp32 only")
+        check(load().cg_allgather_images(self._h, ptr(send), ptr(recv), send.numel(), stream()), "cg_allgather_images")
+
+    def all_reduce_sum_(self, t):
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise HipError("all_reduce_sum_: contiguous fp32 only")
+        check(load().cg_allreduce_sum(self._h, ptr(t), t.numel(), stream()), "cg_allreduce_sum")
+        return t
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, c_void_p()
+            check(load().cg_comm_destroy(h), "cg_comm_destroy")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
+            pass

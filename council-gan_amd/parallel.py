@@ -22,9 +22,12 @@ OTHER members' generated images (trainer_council.py:853-856, 872-874).  So:
     is the full-batch gradient; the two statistics that are not linear in the batch (the squared mask mean of
     the focus loss, the loss-matching history) are averaged before they are used (Council_Trainer).
 
-This module has no dependency on the HIP library: the collectives work on any torch tensor, which
-is what lets the gloo tests exercise them on CPU.  With the gloo backend device tensors are staged through the
-host (gloo is the test transport; RCCL takes device pointers)."""
+By default the collectives go through torch.distributed (backend "nccl" = RCCL on the GPU box), which works on any torch
+tensor and is what lets the gloo tests exercise them on CPU; with the gloo backend device tensors are staged through the
+host (gloo is the test transport; RCCL takes device pointers).  With CG_NATIVE_COLLECTIVES=1 the two data-path
+collectives use the C-ABI instead (include/council_gan_hip.h: cg_comm_*, cg_allgather_images, cg_allreduce_sum --
+communicators of this library's own, enqueued on the CURRENT stream, so they are ordered with the kernels around them
+without an event hand-off); torch.distributed is then only the side channel that distributes the communicator ids."""
 import os
 
 import torch
@@ -35,9 +38,11 @@ def _is_nccl(group):
     return dist.get_backend(group) == "nccl"
 
 
-def _all_gather(recv, send, group):
+def _all_gather(recv, send, group, comm=None):
     """recv[g] = rank g's send (flat views); device tensors go through the host unless the backend is RCCL."""
-    if send.is_cuda and not _is_nccl(group):
+    if comm is not None:
+        comm.all_gather(recv.view(-1), send.view(-1))
+    elif send.is_cuda and not _is_nccl(group):
         r, s = torch.empty(recv.shape, dtype=recv.dtype), send.cpu()
         dist.all_gather_into_tensor(r.view(-1), s.view(-1), group=group)
         recv.copy_(r)
@@ -45,8 +50,10 @@ def _all_gather(recv, send, group):
         dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
 
 
-def _all_reduce_sum(t, group):
-    if t.is_cuda and not _is_nccl(group):
+def _all_reduce_sum(t, group, comm=None):
+    if comm is not None:
+        comm.all_reduce_sum_(t)
+    elif t.is_cuda and not _is_nccl(group):
         h = t.cpu()
         dist.all_reduce(h, group=group)
         t.copy_(h)
@@ -54,8 +61,23 @@ def _all_reduce_sum(t, group):
         dist.all_reduce(t, group=group)
 
 
+def native_comm(group, ranks):
+    """A C-ABI communicator (hip.Comm) over `ranks` (global ranks, in group order) of the torch process group `group`:
+    the group's first rank draws the id, torch.distributed carries it to the others.  Collective over the group."""
+    from . import hip
+    me = dist.get_rank()
+    buf = torch.zeros(hip.COMM_ID_BYTES, dtype=torch.uint8)
+    if me == ranks[0]:
+        buf = torch.tensor(list(hip.comm_unique_id()), dtype=torch.uint8)
+    if _is_nccl(group):
+        buf = buf.cuda()
+    dist.broadcast(buf, src=ranks[0], group=group)
+    return hip.Comm(bytes(buf.cpu().tolist()), ranks.index(me), len(ranks))
+
+
 class CouncilShard:
     def __init__(self, council_size, rank=0, world_size=1, group=None, member_group=None, slice_group=None):
+        self.member_comm = self.slice_comm = None     # C-ABI communicators (use_native_collectives)
         self.council_size = council_size
         self.rank = rank
         self.world_size = world_size
@@ -103,6 +125,19 @@ class CouncilShard:
                 slice_group = g
         return cls(council_size, rank, world, None, member_group, slice_group)
 
+    def use_native_collectives(self):
+        """Route the image exchange and the replica gradient average through the C-ABI communicators (collective: every
+        rank calls it, after its HIP device has been selected).  No-op for a single process."""
+        if self.world_size == 1:
+            return self
+        if self.dp == 1:
+            self.slice_comm = native_comm(self.slice_group, list(range(self.world_size)))
+        else:
+            m, s = self.rank // self.dp, self.slice_idx
+            self.member_comm = native_comm(self.member_group, [m * self.dp + k for k in range(self.dp)])
+            self.slice_comm = native_comm(self.slice_group, [k * self.dp + s for k in range(self.council_size)])
+        return self
+
     def owner(self, member):
         """First rank that holds `member`."""
         return member * self.dp if self.dp > 1 else member // self.per_rank
@@ -120,7 +155,7 @@ class CouncilShard:
     def replica_mean_(self, t):
         """In-place mean over the replicas of this rank's member (gradients, the focus-loss sums, logged losses)."""
         if self.dp > 1:
-            _all_reduce_sum(t, self.member_group)
+            _all_reduce_sum(t, self.member_group, self.member_comm)
             t.mul_(1.0 / self.dp)
         return t
 
@@ -135,7 +170,7 @@ class CouncilShard:
         # stack the PHYSICAL (NHWC) layout so nothing is re-ordered before / after the collective
         send = torch.stack([t.permute(0, 2, 3, 1).contiguous() for t in local_images], 0)
         recv = torch.empty((self.slice_ranks,) + tuple(send.shape), dtype=send.dtype, device=send.device)
-        _all_gather(recv, send, self.slice_group)
+        _all_gather(recv, send, self.slice_group, self.slice_comm)
         me = self.local[0] // self.per_rank
         out = {}
         for r in range(self.slice_ranks):
@@ -152,7 +187,7 @@ class CouncilShard:
             return local
         send = local.permute(0, 2, 3, 1).contiguous()                 # the PHYSICAL (NHWC) layout, untouched
         recv = torch.empty((self.slice_ranks,) + tuple(send.shape), dtype=send.dtype, device=send.device)
-        _all_gather(recv, send, self.slice_group)
+        _all_gather(recv, send, self.slice_group, self.slice_comm)
         return recv.view((-1,) + tuple(send.shape[1:])).permute(0, 3, 1, 2)
 
     def gather_scalars(self, values):

@@ -202,6 +202,8 @@ class Council_Trainer(nn.Module):
             raise hip.HipError("Council_Trainer runs on an MI355X only (got device %s): there is no CPU fallback" % dev)
         torch.cuda.set_device(dev)
         hip.load()
+        if os.environ.get("CG_NATIVE_COLLECTIVES", "0") == "1" and self.shard.slice_comm is None:
+            self.shard.use_native_collectives()       # collective: every rank reaches cuda()
         self.s_a, self.s_b = self.s_a.to(dev), self.s_b.to(dev)
         local = self.shard.local
         for i in local:                  # non-local members stay on the host, untouched

@@ -367,6 +367,26 @@ int cg_gen_total(const float* focus, const float* adv, const float* lc, const fl
                  float council_w, float* total, float* council, float* gcouncil, int nmember, cg_stream_t stream);
 
 
+/* ---- collectives of the sharded path ------------------------------------
+ * One process per GPU.  The reference is single-process: these replace the in-process reads of the other members'
+ * images (trainer_council.py:853-856, 872-874) and, when a member is replicated over several ranks, average its
+ * replicas' gradients.  RCCL (xGMI) is resolved at the first call (the copy already mapped into the process, else
+ * librccl.so.1 from the loader path / the ROCm installation); it is not a link-time dependency of this library.
+ *   cg_comm_unique_id   rank 0 of a group draws the 128-byte id; the host distributes it (any side channel)
+ *   cg_comm_create      every rank of the group, on its own HIP device (collective: returns once all ranks called)
+ *   cg_allgather_images recv[r * elems_per_rank ...] = rank r's send (the local members' comparison images,
+ *                       [members_per_rank * B, H, W, 3] fp32 NHWC), enqueued on `stream`
+ *   cg_allreduce_sum    in place over the flat gradient buffer of a pool (optim.ParamPool), enqueued on `stream` */
+typedef struct cg_comm cg_comm;
+#define CG_COMM_ID_BYTES 128
+int cg_comm_unique_id(unsigned char* id /* CG_COMM_ID_BYTES */);
+int cg_comm_create(const unsigned char* id, int rank, int nranks, cg_comm** comm);
+int cg_comm_destroy(cg_comm* comm);
+int cg_comm_info(const cg_comm* comm, int* rank, int* nranks);
+int cg_allgather_images(cg_comm* comm, const float* send, float* recv, size_t elems_per_rank, cg_stream_t stream);
+int cg_allreduce_sum(cg_comm* comm, float* buf, size_t elems, cg_stream_t stream);
+
+
 /* ---- input pipeline tail on the device ---------------------------------------
  * The last three transforms of the reference's loader (utils.py:124-129,133-134): RandomCrop((H, W)) window,
  * RandomHorizontalFlip, ToTensor + Normalize(mean, std) -- applied to a batch of decoded uint8 images:

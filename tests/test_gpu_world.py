@@ -34,7 +34,9 @@ def _cfg(council):
     return cfg
 
 
-def _worker(rank, world, port, council, q, backend="gloo"):
+def _worker(rank, world, port, council, q, backend="gloo", native=False):
+    if native:
+        os.environ["CG_NATIVE_COLLECTIVES"] = "1"     # the C-ABI communicators instead of torch.distributed's
     import council_gan_amd as cga
     from oracle import council_oracle as O
     dev = 'cuda:0'
@@ -79,11 +81,11 @@ def _worker(rank, world, port, council, q, backend="gloo"):
             dist.destroy_process_group()
 
 
-def _run(world, council, backend="gloo"):
+def _run(world, council, backend="gloo", native=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, council, q, backend)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, council, q, backend, native)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -122,15 +124,45 @@ def test_sharded_trainer_matches_single_process(world, council):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL transport needs two GPUs (this box has one)")
+@pytest.mark.parametrize("native", [False, True], ids=["torch-nccl", "c-abi"])
 @pytest.mark.parametrize("world,council", [(2, 2), (2, 4)])
-def test_sharded_trainer_over_rccl(world, council):
+def test_sharded_trainer_over_rccl(world, council, native):
     """The shipped transport: backend "nccl" = RCCL over xGMI, one GPU per rank -- runs wherever the box has >= 2 GPUs
-    (the driver's multi-GPU node); same criteria as the gloo run above."""
+    (the driver's multi-GPU node); same criteria as the gloo run above.  `c-abi`: the data-path collectives through
+    cg_allgather_images / cg_allreduce_sum (include/council_gan_hip.h) on this library's own communicators."""
     ref = _run(1, council)[0]
-    res = _run(world, council, backend="nccl")
+    res = _run(world, council, backend="nccl", native=native)
     for r in res:
         assert r[1] == res[0][1], "gathered losses differ between ranks"
     for it in range(2):
         for got, want in zip(res[0][1][it], ref[1][it]):
             for g, w in zip(got, want):
                 assert abs(g - w) <= 2e-4 * max(abs(w), 1e-3), (it, got, want)
+
+
+def test_single_rank_communicator_of_the_c_abi():
+    """cg_comm_* / cg_allgather_images / cg_allreduce_sum on the one GPU this box has: a one-rank RCCL communicator
+    (all-gather = copy, all-reduce = identity), enqueued on the current stream -- here a side stream, as the trainer does."""
+    import council_gan_amd as cga  # noqa: F401
+    from council_gan_amd import hip
+    torch.cuda.set_device(0)
+    uid = hip.comm_unique_id()
+    assert len(uid) == hip.COMM_ID_BYTES and uid != hip.comm_unique_id()
+    comm = hip.Comm(uid, 0, 1)
+    try:
+        side = torch.cuda.Stream()
+        x = torch.randn(2 * 4, 64, 64, 3, device="cuda")
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            y = x * 2.0                                   # produced on the side stream, consumed by the collective there
+            recv = torch.empty_like(y)
+            comm.all_gather(recv.view(-1), y.view(-1))
+            g = y.clone()
+            comm.all_reduce_sum_(g.view(-1))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(recv, x * 2.0) and torch.equal(g, x * 2.0)
+        with pytest.raises(hip.HipError):
+            comm.all_gather(torch.empty(3, device="cuda"), y.view(-1))
+    finally:
+        comm.close()

@@ -32,6 +32,26 @@ def test_library_exports_every_declared_symbol():
     assert cga.hip.load().cg_version() >= 100
 
 
+def test_collective_entry_points_resolve_rccl_lazily():
+    """cg_comm_*: RCCL is looked up on first use, not at load time; without a GPU a communicator cannot be created and
+    the call says so instead of crashing (the single- and two-rank runs are -m gpu, tests/test_gpu_world.py)."""
+    hdr = open(os.path.join(ROOT, "include", "council_gan_hip.h")).read()
+    assert int(re.search(r"#define CG_COMM_ID_BYTES (\d+)", hdr).group(1)) == cga.hip.COMM_ID_BYTES
+    try:
+        uid = cga.hip.comm_unique_id()
+    except cga.hip.HipError as e:               # a host without librccl: the message must name the cause
+        assert "RCCL" in str(e)
+        return
+    assert len(uid) == cga.hip.COMM_ID_BYTES
+    with pytest.raises(ValueError):
+        cga.hip.Comm(uid[:5], 0, 1)
+    with pytest.raises(cga.hip.HipError):
+        cga.hip.Comm(uid, 3, 2)                  # rank out of range: argument check, before RCCL is asked
+    if not torch.cuda.is_available():
+        with pytest.raises(cga.hip.HipError):
+            cga.hip.Comm(uid, 0, 1)
+
+
 def test_geometry_struct_matches_header():
     assert ctypes.sizeof(cga.hip.ConvGeom) == 18 * 4 + 2 * 64
 
