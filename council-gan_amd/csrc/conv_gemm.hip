@@ -1401,7 +1401,19 @@ struct WgradPlan {
 // Split plan of ONE member's weight gradient (M = its output rows).  A grouped launch runs the members' identical plans
 // side by side (grid.y), so a member's result does not depend on how many members share the launch; with several members
 // fewer splits per member already fill the chip.
-WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1) {
+// CG_WGRAD_X3_BM256=1 (environment, A/B switch, off by default): the split-precision weight gradient of layers with
+// Cout % 256 == 0 and a 128-wide K-tile runs on a 256 x 128 tile / 16 waves (the shape that pays for the forward kernel
+// from two tiles per CU) instead of 128 x 128 / 8 waves.
+static int wgrad_x3_bm256_state = -1;      // -1: not yet read from the environment
+static bool wgrad_x3_bm256() {
+    if (wgrad_x3_bm256_state < 0) {
+        const char* e = getenv("CG_WGRAD_X3_BM256");
+        wgrad_x3_bm256_state = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return wgrad_x3_bm256_state == 1;
+}
+
+WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1, bool x3 = false) {
     // Every instantiated tile has exactly four 32x32 MFMA wave tiles or more (4 waves / block):
     //   bm=128: bn in {128, 64, 32};  bm=64: bn in {128, 64};  bm=32: bn = 128.
     // FAST (float4 gather, one tap per k-tile) needs a single source and Ct % bn == 0.
@@ -1422,6 +1434,7 @@ WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1) {
         while (p.bn < 128 && p.bn < K) p.bn <<= 1;
         if (p.bn > 128) p.bn = 128;
     }
+    if (x3 && wgrad_x3_bm256() && CG_X3_INTERLEAVE && p.fast && p.bm == 128 && p.bn == 128 && g->Cout % 256 == 0) p.bm = 256;
     p.tiles_m = (g->Cout + p.bm - 1) / p.bm;
     p.tiles_n = (K + p.bn - 1) / p.bn;
     const int slices = (M + 31) / 32;
@@ -1464,7 +1477,7 @@ bool wgrad_pipe_ok(const cg_conv_geom* g, const WgradPlan& p) {
     if (!p.fast || g->C2 != 0 || (g->Cout & 3)) return false;
     if (ilog2_exact(g->Ho * g->Wo) < 0 || ilog2_exact(g->Wo) < 0) return false;
     if (!((p.bm == 128 && p.bn == 128) || (p.bm == 128 && p.bn == 64) || (p.bm == 64 && p.bn == 64) ||
-          (p.bm == 64 && p.bn == 128)))
+          (p.bm == 64 && p.bn == 128) || (p.bm == 256 && p.bn == 128)))     // 256 x 128: split-precision plans only
         return false;
     return (size_t)g->N * g->H * g->W * g->C1 * sizeof(float) < (size_t)CG_OOB &&
            (size_t)g->N * g->Ho * g->Wo * g->Cout * sizeof(float) < (size_t)CG_OOB;
@@ -1693,8 +1706,10 @@ extern "C" int cg_split_f16_dynamic_capped(const float* x, void* out, size_t n, 
 static size_t wgrad_workspace(const cg_conv_geom* g, int nmember) {
     if (!g || g->T < 1 || g->T > CG_MAX_TAPS || nmember < 1 || g->N % nmember) return 0;
     WgradPlan p = plan_wgrad(g, nmember);
+    const WgradPlan px = plan_wgrad(g, nmember, true);     // the split-precision plan may split further (larger tile)
+    const int splits = p.splits > px.splits ? p.splits : px.splits;
     const size_t K = (size_t)g->T * (g->C1 + g->C2);
-    return (size_t)nmember * p.splits * ((size_t)g->Cout * K + g->Cout) * sizeof(float);
+    return (size_t)nmember * splits * ((size_t)g->Cout * K + g->Cout) * sizeof(float);
 }
 extern "C" size_t cg_conv2d_wgrad_workspace(const cg_conv_geom* g) { return wgrad_workspace(g, 1); }
 extern "C" size_t cg_conv2d_wgrad_workspace_g(const cg_conv_geom* g, const cg_group* group) {
@@ -1795,7 +1810,7 @@ static bool wgrad_x3_use_tr() {
 
 static int wgrad_x3_ok(const cg_conv_geom* g, int nmember) {
     if (!g || g->T < 1 || g->T > CG_MAX_TAPS || nmember < 1 || g->N % nmember) return 0;
-    WgradPlan p = plan_wgrad(g, nmember);
+    WgradPlan p = plan_wgrad(g, nmember, true);
     return wgrad_pipe_ok(g, p) && (g->Cout & 31) == 0 && (g->C1 & 31) == 0;
 }
 extern "C" int cg_conv2d_wgrad_x3_ok(const cg_conv_geom* g) { return wgrad_x3_ok(g, 1); }
@@ -1821,7 +1836,7 @@ static int conv2d_wgrad_x3_impl(const cg_conv_geom* g, const cg_group* group, co
                      x3_span(dz_lo_elems, dz_plane) < (size_t)CG_OOB && g->Cout % 32 == 0 && g->C1 % 32 == 0,
                  "%s: operand planes out of range / lo offset does not match the layout", who);
     hipStream_t st = cg_s(stream);
-    WgradPlan p = plan_wgrad(g, gr.n);
+    WgradPlan p = plan_wgrad(g, gr.n, true);
     float* part = (float*)ws;
     const int want_bias = dbias != nullptr;
 #if CG_X3_INTERLEAVE
@@ -1834,6 +1849,10 @@ static int conv2d_wgrad_x3_impl(const cg_conv_geom* g, const cg_group* group, co
     rc = launch_wgrad_x3<BM_, BN_, WM_, WN_>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st, gr.n)
 #endif
     if (p.bm == 128 && p.bn == 128) WGX(128, 128, 64, 32);   // 8 waves
+#if CG_X3_INTERLEAVE
+    else if (p.bm == 256 && p.bn == 128)                     // 16 waves (CG_WGRAD_X3_BM256), transposing-read kernel only
+        rc = launch_wgrad_x3t<256, 128, 64, 32>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st, gr.n);
+#endif
     else if (p.bm == 128 && p.bn == 64) WGX(128, 64, 64, 32);
     else if (p.bm == 64 && p.bn == 64) WGX(64, 64, 32, 32);
     else WGX(64, 128, 32, 64);
@@ -1853,6 +1872,12 @@ extern "C" int cg_conv2d_wgrad_x3_g(const cg_conv_geom* g, const cg_group* group
                                     float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
     return conv2d_wgrad_x3_impl(g, group, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, dw, dbias, accumulate, ws,
                                 ws_bytes, stream, "cg_conv2d_wgrad_x3_g");
+}
+
+extern "C" int cg_conv2d_wgrad_x3_bm256(int on) {      // returns the previous setting; workspace queries follow it
+    const int prev = wgrad_x3_bm256() ? 1 : 0;
+    wgrad_x3_bm256_state = on != 0;
+    return prev;
 }
 
 extern "C" int cg_conv2d_wgrad_legacy(int on) {

@@ -210,6 +210,9 @@ int cg_conv2d_dgrad_g(const cg_conv_geom* g, const cg_group* group, const float*
 
 /* A/B switch: force the non-pipelined weight-gradient kernel (tuning / regression checks only). */
 int cg_conv2d_wgrad_legacy(int on);
+/* A/B switch (also CG_WGRAD_X3_BM256=1 in the environment; off by default): split-precision weight gradients of layers
+ * with Cout % 256 == 0 on a 256 x 128 tile / 16 waves.  Returns the previous setting.  Workspace queries follow it. */
+int cg_conv2d_wgrad_x3_bm256(int on);
 
 /* Weight re-layout for the data-gradient pass: out[ci - ci0][tc][co] = w[co][tapmap[tc]][ci],
  * ci in [ci0, ci0+nci).  w is [Cout][T][Cin]; out is [nci][Tc][Cout]. */

@@ -447,6 +447,65 @@ def test_split_precision_conv_kernels(cga, case):
     assert max(errs.values()) < 2e-5, errs          # fp32-class: the fp32-MFMA kernels sit at ~1e-6 on these shapes
 
 
+@pytest.mark.parametrize("shape", [(4, 16, 16, 256, 256, 3, 1, 1), (6, 9, 16, 128, 512, 4, 2, 1), (3, 8, 8, 512, 256, 1, 1, 0)],
+                         ids=["3x3_256to256", "4x4s2_128to512_ragged_rows", "1x1_512to256"])
+def test_split_precision_weight_gradient_256x128_tile(cga, shape):
+    """The opt-in 256 x 128 / 16-wave tile of conv_wgrad_x3t_kernel (cg_conv2d_wgrad_x3_bm256, CG_WGRAD_X3_BM256): against
+    fp64 and against the default 128 x 128 tile, with the bias gradient, for one member and for a member-batched launch."""
+    from ctypes import byref
+    from council_gan_amd import hip, ops
+    N, H, W, Cin, Cout, K, stride, pad = shape
+    lib = hip.load()
+    g = torch.Generator().manual_seed(7 + Cout + K)
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    gy = torch.randn(N, Cout, Ho, Wo, generator=g, dtype=torch.float64) * 1e-3
+    xd, gyd = cl(dev(x)), cl(dev(gy))
+    geom = ops.fwd_geom(N, H, W, Cin, 0, 0, K, K, stride, pad, Cout, 0)
+
+    def ref(n0, n1):
+        wz = torch.zeros(Cout, Cin, K, K, dtype=torch.float64, requires_grad=True)
+        bz = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+        F.conv2d(F.pad(x[n0:n1], (pad,) * 4), wz, bz, stride=stride).backward(gy[n0:n1])
+        return wz.grad, bz.grad
+
+    def run(nmember):
+        stride_el = Cout * Cin * K * K + Cout + 64          # members' gradients `stride_el` floats apart, as in a pool
+        flat = torch.zeros(nmember * stride_el, device="cuda")
+        grp = hip.Group(nmember, 0, stride_el)
+        with torch.no_grad():
+            xs, dzs = ops.split_f16_dynamic(xd), ops.split_f16_dynamic(gyd)
+            assert lib.cg_conv2d_wgrad_x3_ok_g(byref(geom), byref(grp))
+            wsb = hip.workspace(lib.cg_conv2d_wgrad_workspace_g(byref(geom), byref(grp)))
+            dw, db = flat[:Cout * Cin * K * K], flat[Cout * Cin * K * K:]
+            hip.check(lib.cg_conv2d_wgrad_x3_g(byref(geom), byref(grp), xs.hi_ptr(), xs.lo, xs.scale_ptr(), dzs.hi_ptr(), dzs.lo,
+                                               dzs.scale_ptr(), hip.ptr(dw), hip.ptr(db), 0, hip.ptr(wsb), wsb.numel(),
+                                               hip.stream()), "wgrad_x3_g")
+        torch.cuda.synchronize()
+        out = []
+        for m in range(nmember):
+            o = flat[m * stride_el:(m + 1) * stride_el]
+            out.append((o[:Cout * Cin * K * K].view(Cout, K, K, Cin).permute(0, 3, 1, 2).cpu().double(),
+                        o[Cout * Cin * K * K:Cout * Cin * K * K + Cout].cpu().double()))
+        return out
+
+    members = [1] + ([3] if N % 3 == 0 else [2])
+    prev = lib.cg_conv2d_wgrad_x3_bm256(0)
+    try:
+        base = {n: run(n) for n in members}
+        lib.cg_conv2d_wgrad_x3_bm256(1)
+        wide = {n: run(n) for n in members}
+    finally:
+        lib.cg_conv2d_wgrad_x3_bm256(prev)
+    for n in members:
+        per = N // n
+        for m in range(n):
+            rw, rb = ref(m * per, (m + 1) * per)
+            for got in (base[n][m], wide[n][m]):
+                assert rel(got[0], rw) < 2e-5 and rel(got[1], rb) < 2e-5, (n, m, rel(got[0], rw), rel(got[1], rb))
+            assert rel(wide[n][m][0], base[n][m][0]) < 2e-6
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17, 18, 19])
 def test_split_precision_forward_every_tile_configuration(cga, cfg):
     """Every tile configuration of conv_fwd_x3_kernel the library ships, forced explicitly, on a shape whose row count
