@@ -330,6 +330,164 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// conv_fwd_thin_kernel: forward convolution of the THIN-input layers (3 / 6 / 12 input channels -> 64), exact fp32 MFMA.
+//
+// These layers (the generators' 7x7 first convolution, the discriminators' 4x4 stride-2 first convolution, the council
+// discriminator's two-source 3x3, /root/reference/networks.py:44,152,385-386) have K = taps x channels of 12...147 with
+// three channels per pixel: the implicit-GEMM gather of conv_fwd_kernel pays an address computation, a bounds check and
+// a 4-byte load per A element and re-stages the weights with every K-slice (29-57 TFLOP/s, profiles/r02_h_final_conv_shapes.txt).
+// Here the block is spatial instead:
+//   * a block owns 16 x 16 output pixels x all 64 output channels of one image at a time and walks a strided list of
+//     such tiles (persistent: grid.x blocks per member);
+//   * the input PATCH of a tile -- ((16-1)*S + KH) x ((16-1)*S + KW) pixels x CT channels, zero outside the image, both
+//     sources of a two-source layer interleaved per pixel -- is copied into LDS once, with coalesced row loads;
+//   * the weights never pass through LDS in the loop: every lane keeps ITS column of B (output channel wn*32 + lane%32,
+//     k = 2*kp + lane/32) for the whole K range in registers (K/2 VGPRs), loaded once per block;
+//   * an A element is then ONE ds_read_b32 at patch[row base + koff(k)], koff a compile-time constant of the unrolled
+//     K loop: no address arithmetic, no bounds checks, no barrier inside the K loop.
+// 8 waves: wave (wm, wn) computes rows [64 wm, 64 wm + 64) x channels [32 wn, 32 wn + 32) with v_mfma_f32_32x32x2_f32.
+// Taps must be the regular KH x KW raster (dy = kh - pad_y, dx = kw - pad_x), no upsampled source, plain output grid.
+// ------------------------------------------------------------------------------------------
+template <int KH, int KW, int CT, int S>
+__global__ __launch_bounds__(512) void conv_fwd_thin_kernel(
+    cg_conv_geom g, const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ w,
+    const float* __restrict__ bias, float* __restrict__ y, int imgs_per_member, int pad_y, int pad_x,
+    float* __restrict__ amax_state, Members mb) {
+    constexpr int TH = 16, TW = 16, NT = 512, BN = 64;
+    // K runs over (kh, j), j = kw * CT + c: inside one kernel row the patch offsets of consecutive k are consecutive, so an
+    // MFMA (two k's: lane / 32 selects which) takes the pair j = 2 jp, 2 jp + 1 of one row -- the upper half-wave's LDS
+    // address is the lower one's + 1 and everything else is an immediate.  An odd row length pads its last pair with a
+    // zero weight (7x7x3: 77 MFMAs for 147 k's).
+    constexpr int K = KH * KW * CT, RL = KW * CT, JP = (RL + 1) / 2, KP = KH * JP;
+    constexpr int KS = K | 1;                                  // odd row stride of the weights in LDS: 32 channels, 32 banks
+    constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, PN = PH * PW * CT;
+    constexpr int PV = (PN + NT - 1) / NT;                      // patch elements per thread
+    __shared__ float wl[BN * KS + 1];
+    __shared__ float patch[2][PN + 4];                          // + zeroed pad words: a padded pair may read one element past
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w) + (long long)blockIdx.z * mb.w_stride);
+    if (bias) bias = reinterpret_cast<const float*>(reinterpret_cast<const char*>(bias) + (long long)blockIdx.z * mb.b_stride);
+
+    // this lane's column of B, once per block: w is [Cout][K] (K = (kh, kw, c) raster, c over source 1 then source 2)
+    for (int idx = tid; idx < BN * K; idx += NT) {
+        const int col = idx / K, k = idx - col * K;
+        wl[col * KS + k] = w[idx];
+    }
+    if (tid == 0) wl[BN * KS] = 0.f;
+    if (tid < 8) patch[tid >> 2][PN + (tid & 3)] = 0.f;
+    __syncthreads();
+    float breg[KP];
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+        const int j = 2 * (kp % JP) + lh;
+        const float v = wl[(wn * 32 + l31) * KS + (kp / JP) * RL + j];   // j == RL (padded pair) reads the next k / the pad word
+        breg[kp] = j < RL ? v : 0.f;
+    }
+    const float bj = bias ? bias[wn * 32 + l31] : 0.f;
+
+    // LDS offsets of this lane's two A rows: row r of the tile is pixel (r / 16, r % 16)
+    int rb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + i * 32 + l31;
+        rb[i] = (((r >> 4) * S) * PW + (r & 15) * S) * CT + lh;
+    }
+
+    const int tiles_x = (g.Wo + TW - 1) / TW, tiles_y = (g.Ho + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y, ntiles = imgs_per_member * tiles_img;
+    const int img0 = (int)blockIdx.z * imgs_per_member;
+    float vmax = 0.f;
+    // the patch of the NEXT tile travels through registers while the current one is multiplied (two LDS buffers, one
+    // barrier per tile)
+    float pv[PV];
+    auto fetch_patch = [&](int t) {
+        const int n = img0 + t / tiles_img, tr = t % tiles_img;
+        const int iy0 = (tr / tiles_x) * TH * S - pad_y, ix0 = (tr % tiles_x) * TW * S - pad_x;
+#pragma unroll
+        for (int j = 0; j < PV; ++j) {
+            const int e = tid + j * NT;
+            const int pix = e / CT, c = e - pix * CT;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            float v = 0.f;
+            if (e < PN && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) {
+                const size_t p = ((size_t)n * g.H + iy) * g.W + ix;
+                v = c < g.C1 ? x1[p * g.C1 + c] : x2[p * g.C2 + (c - g.C1)];
+            }
+            pv[j] = v;
+        }
+    };
+    auto store_patch = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < PV; ++j) {
+            const int e = tid + j * NT;
+            if (e < PN) patch[buf][e] = pv[j];
+        }
+    };
+    int cur = 0;
+    if ((int)blockIdx.x < ntiles) {
+        fetch_patch(blockIdx.x);
+        store_patch(0);
+    }
+    __syncthreads();
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int n = img0 + t / tiles_img, tr = t % tiles_img;
+        const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+        const bool more = t + (int)gridDim.x < ntiles;
+        if (more) fetch_patch(t + gridDim.x);                   // global loads in flight under the MFMAs below
+        const float* __restrict__ pt = patch[cur];
+
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        // A elements are fetched DEPTH k-pairs ahead of the MFMAs that consume them (register ring, static indices)
+        constexpr int DEPTH = KP < 4 ? KP : 4;
+        auto a_off = [&](int kp) { return (kp / JP) * (PW * CT) + 2 * (kp % JP); };      // compile-time after unrolling
+        float a0[DEPTH], a1[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int off = a_off(d);
+            a0[d] = pt[rb[0] + off];
+            a1[d] = pt[rb[1] + off];
+        }
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            const float u0 = a0[kp % DEPTH], u1 = a1[kp % DEPTH];
+            if (kp + DEPTH < KP) {
+                const int off = a_off(kp + DEPTH);
+                a0[kp % DEPTH] = pt[rb[0] + off];
+                a1[kp % DEPTH] = pt[rb[1] + off];
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(u0, breg[kp], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(u1, breg[kp], acc1, 0, 0, 0);
+        }
+
+        // C/D layout of the 32x32 MFMA: col = lane % 32, row = (r & 3) + 8 * (r >> 2) + 4 * (lane / 32)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+                if (oy < g.Ho && ox < g.Wo) {
+                    const float v = cg_apply_act((i ? acc1[r] : acc0[r]) + bj, g.act);
+                    y[(((size_t)n * g.Ho + oy) * g.Wo + ox) * BN + wn * 32 + l31] = v;
+                    vmax = fmaxf(vmax, fabsf(v));
+                }
+            }
+        }
+        if (more) store_patch(cur ^ 1);                         // last read by the previous tile, released by its barrier
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (amax_state) block_amax_store<NT>(vmax, amax_state);
+}
+
+// ------------------------------------------------------------------------------------------
 // forward / data-gradient kernel, software-pipelined ("pipe") -- the hot one.
 //
 // Same GEMM view and LDS image as conv_fwd_kernel<.., FAST>, restricted to single-source inputs whose
@@ -1179,9 +1337,9 @@ struct ProfScope {
                      bn, g->N, g->H, g->W, g->C1 + g->C2, g->Cout, g->T, g->stride, g->up, g->Ho, g->Wo, ncls);
         rec.slot = family * 20 + tile_id(bm, bn) * 2 + (fast ? 1 : 0);
         rec.flops = flops;
-        static const char* const fam[8] = {"conv_fwd_kernel",    "conv_wgrad_kernel",    "conv_fwd_pipe_kernel",
-                                           "conv_wgrad_pipe_kernel", "conv_fwd_x3_kernel", "conv_wgrad_x3_kernel",
-                                           "conv_fwd_x3w_kernel", "conv_wgrad_x3t_kernel"};
+        static const char* const fam[9] = {"conv_fwd_kernel",     "conv_wgrad_kernel",     "conv_fwd_pipe_kernel",
+                                           "conv_wgrad_pipe_kernel", "conv_fwd_x3_kernel",  "conv_wgrad_x3_kernel",
+                                           "conv_fwd_x3w_kernel", "conv_wgrad_x3t_kernel", "conv_fwd_thin_kernel"};
         snprintf(prof_names[rec.slot], sizeof(prof_names[0]), "%s<%d,%d,%s>", fam[family], bm, bn, fast ? "fast" : "generic");
         (void)hipEventCreate(&rec.e0);
         (void)hipEventCreate(&rec.e1);
@@ -1334,6 +1492,70 @@ bool pipe_ok(const cg_conv_geom* g, int K) {
            (size_t)g->Cout * K * sizeof(float) < (size_t)CG_OOB;
 }
 
+// ---- thin-input layers (conv_fwd_thin_kernel) -----------------------------------------------------------------------
+// CG_FWD_THIN=1 in the environment / cg_conv2d_fwd_thin(1): layers that match a compiled (KH, KW, channels, stride) variant
+// run on the spatial-tile kernel (tile configuration 40); off by default until measured in the step.
+static int fwd_thin_state = -1;
+static bool fwd_thin_on() {
+    if (fwd_thin_state < 0) {
+        const char* e = getenv("CG_FWD_THIN");
+        fwd_thin_state = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return fwd_thin_state == 1;
+}
+
+struct ThinVariant { int kh, kw, ct, s; };
+static const ThinVariant thin_variants[] = {{7, 7, 3, 1}, {4, 4, 3, 2}, {3, 3, 6, 1}, {3, 3, 3, 1}, {1, 1, 12, 1}};
+
+// index into thin_variants, or -1
+static int thin_match(const cg_conv_geom* g) {
+    if (g->up != 0 || g->osy != 1 || g->osx != 1 || g->ooy != 0 || g->oox != 0 || g->HoF != g->Ho || g->WoF != g->Wo) return -1;
+    if (g->Cout != 64) return -1;
+    const int ct = g->C1 + g->C2;
+    for (int v = 0; v < (int)(sizeof(thin_variants) / sizeof(thin_variants[0])); ++v) {
+        const ThinVariant& tv = thin_variants[v];
+        if (g->T != tv.kh * tv.kw || ct != tv.ct || g->stride != tv.s) continue;
+        bool raster = true;
+        for (int t = 0; t < g->T && raster; ++t)
+            raster = g->dy[t] == g->dy[0] + t / tv.kw && g->dx[t] == g->dx[0] + t % tv.kw;
+        if (raster) return v;
+    }
+    return -1;
+}
+
+template <int KH, int KW, int CT, int S>
+int launch_fwd_thin(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias, float* y, int M,
+                    hipStream_t st, const Grp& gr) {
+    const int imgs = M / (g->Ho * g->Wo);                       // images of ONE member
+    const int ntiles = imgs * ((g->Ho + 15) / 16) * ((g->Wo + 15) / 16);
+    int gx = 512 / gr.n;                                        // two resident blocks per CU over all members
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    dim3 grid(gx, 1, gr.n), block(512);
+    float* amax = nullptr;
+    if (fwd_amax.state) {
+        fwd_amax.nslots = amax_slots_for((long)gx * gr.n, fwd_amax.state, st);
+        if (fwd_amax.nslots) amax = fwd_amax.state;
+    }
+    ProfScope prof(8, 256, 64, true, 2.0 * (double)M * gr.n * 64.0 * (double)(KH * KW * CT), st, g, gr.n);
+    hipLaunchKernelGGL((conv_fwd_thin_kernel<KH, KW, CT, S>), grid, block, 0, st, *g, x1, x2, w, bias, y, imgs, -(int)g->dy[0],
+                       -(int)g->dx[0], amax, members_f32(gr));
+    CG_LAUNCH_CHECK("conv_fwd_thin_kernel");
+    return CG_OK;
+}
+
+int launch_fwd_thin_variant(int v, const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
+                            float* y, int M, hipStream_t st, const Grp& gr) {
+    switch (v) {
+        case 0: return launch_fwd_thin<7, 7, 3, 1>(g, x1, x2, w, bias, y, M, st, gr);
+        case 1: return launch_fwd_thin<4, 4, 3, 2>(g, x1, x2, w, bias, y, M, st, gr);
+        case 2: return launch_fwd_thin<3, 3, 6, 1>(g, x1, x2, w, bias, y, M, st, gr);
+        case 3: return launch_fwd_thin<3, 3, 3, 1>(g, x1, x2, w, bias, y, M, st, gr);
+        case 4: return launch_fwd_thin<1, 1, 12, 1>(g, x1, x2, w, bias, y, M, st, gr);
+        default: return cg_set_error(CG_ERR_ARG, "thin conv: no such variant");
+    }
+}
+
 // tile configurations of the forward kernel (id -> BM, BN, WM, WN, STAGES); M = rows of one member
 int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
                    float* y, int M, int K, bool fast, hipStream_t st, double* stats, const Grp& gr) {
@@ -1365,6 +1587,11 @@ int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float*
             return launch_pipe_cfg(cfg, b, 1, x1, bias, y, (unsigned)((size_t)g->N * g->H * g->W * g->C1 * sizeof(float)), st,
                                    stats, members_f32(gr));
         }
+        case 40: {
+            const int v = thin_match(g);
+            if (v < 0) return cg_set_error(CG_ERR_ARG, "conv forward: configuration 40 needs a thin-input layer (3/6/12 -> 64 channels)");
+            return launch_fwd_thin_variant(v, g, x1, x2, w, bias, y, M, st, gr);
+        }
         default: return cg_set_error(CG_ERR_ARG, "conv forward: unknown tile configuration %d", cfg);
     }
 #undef FW
@@ -1374,6 +1601,7 @@ int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float*
 // other's barrier / LDS phases) reach 112-123 TFLOP/s once >= ~192 such tiles exist; problems with
 // fewer tiles fill the 256 CUs better with 64x64 tiles (two LDS stages when very few tiles).  M = rows of the LAUNCH.
 int pick_fwd_cfg(const cg_conv_geom* g, long M, bool pipe) {
+    if (fwd_thin_on() && thin_match(g) >= 0) return 40;
     const long blocks128 = ((M + 127) / 128) * ((g->Cout + 127) / 128);
     if (g->Cout > 64) {
         if (blocks128 >= 192) return pipe ? 20 : 6;
@@ -1872,6 +2100,12 @@ extern "C" int cg_conv2d_wgrad_x3_g(const cg_conv_geom* g, const cg_group* group
                                     float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
     return conv2d_wgrad_x3_impl(g, group, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, dw, dbias, accumulate, ws,
                                 ws_bytes, stream, "cg_conv2d_wgrad_x3_g");
+}
+
+extern "C" int cg_conv2d_fwd_thin(int on) {             // returns the previous setting
+    const int prev = fwd_thin_on() ? 1 : 0;
+    fwd_thin_state = on != 0;
+    return prev;
 }
 
 extern "C" int cg_conv2d_wgrad_x3_bm256(int on) {      // returns the previous setting; workspace queries follow it

@@ -386,6 +386,97 @@ def test_no_cpu_fallback(cga):
 
 
 # ------------------------------------------------------------------------------------------
+# thin-input layers on the spatial-tile kernel (conv_fwd_thin_kernel, tile configuration 40 / cg_conv2d_fwd_thin)
+# ------------------------------------------------------------------------------------------
+THIN_CASES = [
+    # name, N, H, W, C1, C2, K, stride, pad, act  (sizes that are multiples of no tile edge)
+    ("gen_7x7_3to64", 2, 40, 24, 3, 0, 7, 1, 3, "none"),
+    ("dis_4x4s2_3to64", 3, 36, 20, 3, 0, 4, 2, 1, "lrelu"),
+    ("council_dis_3x3_3+3to64", 2, 20, 33, 3, 3, 3, 1, 1, "lrelu"),
+    ("3x3_3to64", 1, 16, 16, 3, 0, 3, 1, 1, "relu"),
+    ("1x1_12to64", 2, 17, 16, 12, 0, 1, 1, 0, "none"),
+    ("gen_7x7_3to64_full_tiles", 4, 32, 32, 3, 0, 7, 1, 3, "none"),
+]
+
+
+@pytest.mark.parametrize("case", THIN_CASES, ids=[c[0] for c in THIN_CASES])
+def test_thin_input_convolution(cga, case):
+    """Forced (configuration 40) against fp64 and against the generic kernel; then through ops.conv2d with the switch on:
+    a member-batched launch equals the members' own launches bit for bit, the reported block maxima bound the output
+    exactly, and layers that do not match a variant keep their kernel."""
+    from ctypes import byref
+    from council_gan_amd import hip, ops
+    _, N, H, W, C1, C2, K, stride, pad, act = case
+    lib = hip.load()
+    g = torch.Generator().manual_seed(sum(map(ord, case[0])))
+    Ct = C1 + C2
+    x = torch.randn(N, Ct, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(64, Ct, K, K, generator=g, dtype=torch.float64) / np.sqrt(Ct * K * K)
+    b = torch.randn(64, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.pad(x, (pad,) * 4), w, b, stride=stride)
+    ref = {"none": ref, "relu": F.relu(ref), "lrelu": F.leaky_relu(ref, 0.2)}[act]
+    x1d = cl(dev(x[:, :C1]))
+    x2d = cl(dev(x[:, C1:])) if C2 else None
+    wd, bd = cl(dev(w)), dev(b)
+    geom = ops.fwd_geom(N, H, W, C1, C2, 0, K, K, stride, pad, 64, ops.ACT[act])
+
+    def forced(cfg):
+        y = torch.full((N, 64, geom.Ho, geom.Wo), float("nan"), device="cuda").contiguous(memory_format=torch.channels_last)
+        hip.check(lib.cg_conv2d_fwd_tile(byref(geom), hip.ptr(x1d), hip.ptr(x2d), hip.ptr(wd), hip.ptr(bd), hip.ptr(y), cfg,
+                                         hip.stream()), "cg_conv2d_fwd_tile")
+        return y
+    thin, generic = forced(40), forced(1)
+    assert rel(thin, ref) < 3e-6, rel(thin, ref)
+    assert rel(thin, generic) < 2e-6
+
+    prev = lib.cg_conv2d_fwd_thin(1)
+    try:
+        with torch.no_grad():
+            flags = (ops.X3_FORWARD, ops.X3_DYNAMIC_INPUT)
+            ops.X3_FORWARD = ops.X3_DYNAMIC_INPUT = True       # the split-precision consumers ask producers for block maxima
+            try:
+                y = ops.conv2d(x1d, wd, bd, stride, pad, act, x2=x2d)
+            finally:
+                ops.X3_FORWARD, ops.X3_DYNAMIC_INPUT = flags
+            assert torch.equal(y, thin)
+            state, nslots = y._cg_amax
+            assert float(state[2:2 + nslots].max()) == float(y.abs().max())
+            # a layer no variant covers (32 output channels) keeps the generic kernel
+            w32 = cl(dev(w[:32]))
+            y32 = ops.conv2d(x1d, w32, bd[:32], stride, pad, act, x2=x2d)
+            assert rel(y32, ref[:, :32]) < 3e-6
+        # member-batched: two members' weights one pool stride apart, their samples stacked along the batch
+        if N % 2 == 0:
+            w2 = torch.randn(64, Ct, K, K, generator=g, dtype=torch.float64) / np.sqrt(Ct * K * K)
+            b2 = torch.randn(64, generator=g, dtype=torch.float64)
+            nw = wd.numel()
+            stride_el = nw + 64 + 32
+            pool = torch.zeros(2 * stride_el, device="cuda")
+            for m, (wm_, bm_) in enumerate(((w, b), (w2, b2))):
+                pool[m * stride_el:m * stride_el + nw] = dev(wm_).permute(0, 2, 3, 1).reshape(-1)
+                pool[m * stride_el + nw:m * stride_el + nw + 64] = dev(bm_)
+            grp = hip.Group(2, 0, stride_el)
+            yg = torch.full_like(thin, float("nan"))
+            hip.check(lib.cg_conv2d_fwd_g(byref(geom), byref(grp), hip.ptr(x1d), hip.ptr(x2d), hip.ptr(pool[:nw]),
+                                          hip.ptr(pool[nw:nw + 64]), hip.ptr(yg), None, 0, None, None, None, hip.stream()),
+                      "cg_conv2d_fwd_g")
+            h = N // 2
+            gh = ops.fwd_geom(h, H, W, C1, C2, 0, K, K, stride, pad, 64, ops.ACT[act])
+            for m, (wm_, bm_) in enumerate(((w, b), (w2, b2))):
+                ym = torch.full((h, 64, geom.Ho, geom.Wo), float("nan"), device="cuda").contiguous(memory_format=torch.channels_last)
+                xa = x1d[m * h:(m + 1) * h]
+                xb = x2d[m * h:(m + 1) * h] if C2 else None
+                hip.check(lib.cg_conv2d_fwd_tile(byref(gh), hip.ptr(xa), hip.ptr(xb), hip.ptr(cl(dev(wm_))), hip.ptr(dev(bm_)),
+                                                 hip.ptr(ym), 40, hip.stream()), "cg_conv2d_fwd_tile")
+                assert torch.equal(yg[m * h:(m + 1) * h], ym)
+                refm = F.conv2d(F.pad(x[m * h:(m + 1) * h], (pad,) * 4), wm_, bm_, stride=stride)
+                refm = {"none": refm, "relu": F.relu(refm), "lrelu": F.leaky_relu(refm, 0.2)}[act]
+                assert rel(ym, refm) < 3e-6
+    finally:
+        lib.cg_conv2d_fwd_thin(prev)
+
+
+# ------------------------------------------------------------------------------------------
 # split-precision (fp16 x 3) kernels: forward, data gradient, weight gradient -- against fp64, with operands whose
 # magnitude is far outside fp16's comfortable range (the device-side power-of-two scale must absorb it)
 # ------------------------------------------------------------------------------------------
@@ -506,7 +597,7 @@ def test_split_precision_weight_gradient_256x128_tile(cga, shape):
             assert rel(wide[n][m][0], base[n][m][0]) < 2e-6
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17, 18, 19, 20, 21])
 def test_split_precision_forward_every_tile_configuration(cga, cfg):
     """Every tile configuration of conv_fwd_x3_kernel the library ships, forced explicitly, on a shape whose row count
     (960) and channel count (160) are multiples of no tile edge, with bias + LeakyReLU in the epilogue."""
