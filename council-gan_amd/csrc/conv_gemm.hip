@@ -488,6 +488,149 @@ __global__ __launch_bounds__(512) void conv_fwd_thin_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// conv_wgrad_thin_kernel: weight (+ bias) gradient of the same thin-input layers, exact fp32 MFMA.
+//   dW[co][k] = sum over output pixels of dz[pix][co] * patch[pix][k]
+// Same spatial blocking as conv_fwd_thin_kernel (16 x 16 output pixels of one image per step, persistent over a strided
+// tile list), with the reduction index on the MFMA's K: per pixel pair (2p, 2p + 1) the A operand is dz (row = output
+// channel) and the B operand is the input patch gathered at this lane's own k (column = k; its patch offset is
+// computed once per lane, the pixel pair's is an immediate of the unrolled loop).  Wave w owns output channels
+// [32 (w & 1), +32) x all k-tiles for the pixel rows [4 (w >> 1), +4) of a tile, keeps its accumulators for the block's
+// whole tile list, and the four pixel slices are summed through LDS at the very end in a fixed order.  A block is one
+// split: partial layout and the final reduce are conv_wgrad_kernel's (splitk_reduce_kernel).
+// ------------------------------------------------------------------------------------------
+template <int KH, int KW, int CT, int S>
+__global__ __launch_bounds__(512) void conv_wgrad_thin_kernel(
+    cg_conv_geom g, const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ dz,
+    float* __restrict__ part, int imgs_per_member, int pad_y, int pad_x, int want_bias) {
+    constexpr int TH = 16, TW = 16, NT = 512, CO = 64;
+    constexpr int K = KH * KW * CT, NKT = (K + 31) / 32;
+    constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, PN = PH * PW * CT;
+    constexpr int PV = (PN + NT - 1) / NT;                      // patch elements per thread
+    constexpr int DZN = TH * TW * CO, DV = DZN / 4 / NT;        // dz tile: floats, float4 per thread
+    static_assert(2 * NKT * 1024 + CO <= DZN, "the final reduction reuses the dz tile");
+    __shared__ __attribute__((aligned(16))) float dzl[DZN];
+    __shared__ float patch[PN + 4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int cot = wid & 1, slice = wid >> 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // this lane's column k of every k-tile -> offset inside a patch (k >= K: any valid offset, never stored)
+    int koff[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int k = kt * 32 + l31;
+        const int kk = k < K ? k : 0;
+        const int tap = kk / CT, c = kk - tap * CT;
+        koff[kt] = ((tap / KW) * PW + (tap % KW)) * CT + c;
+    }
+    // pixel 64 slice + 2 q + lh of the tile: (py, px) = (4 slice + q / 8, 2 (q % 8) + lh)
+    const int pbase = ((4 * slice * S) * PW) * CT + lh * S * CT;           // + the immediate of q below
+    const int abase = (64 * slice + lh) * CO + cot * 32 + l31;             // + 2 q CO
+
+    const int tiles_x = (g.Wo + TW - 1) / TW, tiles_y = (g.Ho + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y, ntiles = imgs_per_member * tiles_img;
+    const int img0 = (int)blockIdx.z * imgs_per_member;
+
+    float pv[PV];
+    float4 dv[DV];
+    auto fetch = [&](int t) {
+        const int n = img0 + t / tiles_img, tr = t % tiles_img;
+        const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+        const int iy0 = oy0 * S - pad_y, ix0 = ox0 * S - pad_x;
+#pragma unroll
+        for (int j = 0; j < PV; ++j) {
+            const int e = tid + j * NT;
+            const int pix = e / CT, c = e - pix * CT;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            float v = 0.f;
+            if (e < PN && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) {
+                const size_t p = ((size_t)n * g.H + iy) * g.W + ix;
+                v = c < g.C1 ? x1[p * g.C1 + c] : x2[p * g.C2 + (c - g.C1)];
+            }
+            pv[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < DV; ++j) {
+            const int f = tid + j * NT;                          // float4 f of the tile: pixel f / 16, channels 4 (f % 16) ..
+            const int pix = f >> 4, c4 = f & 15;
+            const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oy < g.Ho && ox < g.Wo)
+                v = *reinterpret_cast<const float4*>(dz + (((size_t)n * g.Ho + oy) * g.Wo + ox) * CO + c4 * 4);
+            dv[j] = v;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < PV; ++j) {
+            const int e = tid + j * NT;
+            if (e < PN) patch[e] = pv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < DV; ++j) *reinterpret_cast<float4*>(&dzl[(tid + j * NT) * 4]) = dv[j];
+    };
+
+    f32x16 acc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kt][r] = 0.f;
+    float bsum = 0.f;
+
+    if (tid < 4) patch[PN + tid] = 0.f;
+    fetch(blockIdx.x);                                          // the launcher guarantees gridDim.x <= ntiles
+    stash();
+    __syncthreads();
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const bool more = t + (int)gridDim.x < ntiles;
+        if (more) fetch(t + gridDim.x);                         // global loads in flight under the MFMAs below
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const float a = dzl[abase + 2 * q * CO];
+            bsum += a;
+            const int pq = ((q >> 3) * S * PW + 2 * (q & 7) * S) * CT;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, patch[pbase + pq + koff[kt]], acc[kt], 0, 0, 0);
+        }
+        __syncthreads();                                        // every wave is done with this tile's LDS image
+        if (more) stash();
+        __syncthreads();
+    }
+
+    // sum the four pixel slices in a fixed order: red[(cot * NKT + kt) * 16 + r][lane], then the bias row
+    float* red = dzl;
+    const float bs = bsum + __shfl_xor(bsum, 32, 64);
+    for (int rnd = 0; rnd < 4; ++rnd) {
+        if (slice == rnd) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int idx = ((cot * NKT + kt) * 16 + r) * 64 + lane;
+                    red[idx] = (rnd ? red[idx] : 0.f) + acc[kt][r];
+                }
+            if (lh == 0) {
+                const int idx = 2 * NKT * 1024 + cot * 32 + l31;
+                red[idx] = (rnd ? red[idx] : 0.f) + bs;
+            }
+        }
+        __syncthreads();
+    }
+    float* dst = part + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * ((size_t)CO * K + CO);   // per (member, split)
+    for (int e = tid; e < CO * K; e += NT) {
+        const int co = e / K, k = e - co * K;
+        const int row = co & 31, col = k & 31;
+        // C/D layout of the 32x32 MFMA: lane = col + 32 * ((row >> 2) & 1), register (row & 3) + 4 * (row >> 3)
+        dst[e] = red[(((co >> 5) * NKT + (k >> 5)) * 16 + (row & 3) + 4 * (row >> 3)) * 64 + col + 32 * ((row >> 2) & 1)];
+    }
+    if (want_bias && tid < CO) dst[(size_t)CO * K + tid] = red[2 * NKT * 1024 + tid];
+}
+
+// ------------------------------------------------------------------------------------------
 // forward / data-gradient kernel, software-pipelined ("pipe") -- the hot one.
 //
 // Same GEMM view and LDS image as conv_fwd_kernel<.., FAST>, restricted to single-source inputs whose
@@ -1337,9 +1480,10 @@ struct ProfScope {
                      bn, g->N, g->H, g->W, g->C1 + g->C2, g->Cout, g->T, g->stride, g->up, g->Ho, g->Wo, ncls);
         rec.slot = family * 20 + tile_id(bm, bn) * 2 + (fast ? 1 : 0);
         rec.flops = flops;
-        static const char* const fam[9] = {"conv_fwd_kernel",     "conv_wgrad_kernel",     "conv_fwd_pipe_kernel",
+        static const char* const fam[10] = {"conv_fwd_kernel",     "conv_wgrad_kernel",     "conv_fwd_pipe_kernel",
                                            "conv_wgrad_pipe_kernel", "conv_fwd_x3_kernel",  "conv_wgrad_x3_kernel",
-                                           "conv_fwd_x3w_kernel", "conv_wgrad_x3t_kernel", "conv_fwd_thin_kernel"};
+                                           "conv_fwd_x3w_kernel", "conv_wgrad_x3t_kernel", "conv_fwd_thin_kernel",
+                                           "conv_wgrad_thin_kernel"};
         snprintf(prof_names[rec.slot], sizeof(prof_names[0]), "%s<%d,%d,%s>", fam[family], bm, bn, fast ? "fast" : "generic");
         (void)hipEventCreate(&rec.e0);
         (void)hipEventCreate(&rec.e1);
@@ -1553,6 +1697,48 @@ int launch_fwd_thin_variant(int v, const cg_conv_geom* g, const float* x1, const
         case 3: return launch_fwd_thin<3, 3, 3, 1>(g, x1, x2, w, bias, y, M, st, gr);
         case 4: return launch_fwd_thin<1, 1, 12, 1>(g, x1, x2, w, bias, y, M, st, gr);
         default: return cg_set_error(CG_ERR_ARG, "thin conv: no such variant");
+    }
+}
+
+// weight gradient of the thin-input layers (conv_wgrad_thin_kernel): CG_WGRAD_THIN=1 / cg_conv2d_wgrad_thin(1), off by default
+static int wgrad_thin_state = -1;
+static bool wgrad_thin_on() {
+    if (wgrad_thin_state < 0) {
+        const char* e = getenv("CG_WGRAD_THIN");
+        wgrad_thin_state = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return wgrad_thin_state == 1;
+}
+// blocks (= splits) per member of a thin weight-gradient launch; M = rows of one member
+static int thin_wgrad_splits(const cg_conv_geom* g, int nmember) {
+    const int imgs = g->N / nmember;
+    const int ntiles = imgs * ((g->Ho + 15) / 16) * ((g->Wo + 15) / 16);
+    int gx = 256 / nmember;                                     // one resident block per CU over all members
+    if (gx < 1) gx = 1;
+    return gx < ntiles ? gx : ntiles;
+}
+
+template <int KH, int KW, int CT, int S>
+int launch_wgrad_thin(const cg_conv_geom* g, const float* x1, const float* x2, const float* dz, float* part, int want_bias,
+                      hipStream_t st, int nmember) {
+    const int imgs = g->N / nmember;
+    dim3 grid(thin_wgrad_splits(g, nmember), 1, nmember), block(512);
+    ProfScope prof(9, 256, 64, true, 2.0 * (double)g->N * g->Ho * g->Wo * 64.0 * (double)(KH * KW * CT), st, g, nmember);
+    hipLaunchKernelGGL((conv_wgrad_thin_kernel<KH, KW, CT, S>), grid, block, 0, st, *g, x1, x2, dz, part, imgs, -(int)g->dy[0],
+                       -(int)g->dx[0], want_bias);
+    CG_LAUNCH_CHECK("conv_wgrad_thin_kernel");
+    return CG_OK;
+}
+
+int launch_wgrad_thin_variant(int v, const cg_conv_geom* g, const float* x1, const float* x2, const float* dz, float* part,
+                              int want_bias, hipStream_t st, int nmember) {
+    switch (v) {
+        case 0: return launch_wgrad_thin<7, 7, 3, 1>(g, x1, x2, dz, part, want_bias, st, nmember);
+        case 1: return launch_wgrad_thin<4, 4, 3, 2>(g, x1, x2, dz, part, want_bias, st, nmember);
+        case 2: return launch_wgrad_thin<3, 3, 6, 1>(g, x1, x2, dz, part, want_bias, st, nmember);
+        case 3: return launch_wgrad_thin<3, 3, 3, 1>(g, x1, x2, dz, part, want_bias, st, nmember);
+        case 4: return launch_wgrad_thin<1, 1, 12, 1>(g, x1, x2, dz, part, want_bias, st, nmember);
+        default: return cg_set_error(CG_ERR_ARG, "thin weight gradient: no such variant");
     }
 }
 
@@ -1935,7 +2121,11 @@ static size_t wgrad_workspace(const cg_conv_geom* g, int nmember) {
     if (!g || g->T < 1 || g->T > CG_MAX_TAPS || nmember < 1 || g->N % nmember) return 0;
     WgradPlan p = plan_wgrad(g, nmember);
     const WgradPlan px = plan_wgrad(g, nmember, true);     // the split-precision plan may split further (larger tile)
-    const int splits = p.splits > px.splits ? p.splits : px.splits;
+    int splits = p.splits > px.splits ? p.splits : px.splits;
+    if (wgrad_thin_on() && thin_match(g) >= 0) {
+        const int ts = thin_wgrad_splits(g, nmember);
+        if (ts > splits) splits = ts;
+    }
     const size_t K = (size_t)g->T * (g->C1 + g->C2);
     return (size_t)nmember * splits * ((size_t)g->Cout * K + g->Cout) * sizeof(float);
 }
@@ -1963,6 +2153,11 @@ static int conv2d_wgrad_impl(const cg_conv_geom* g, const cg_group* group, const
     WgradPlan p = plan_wgrad(g, gr.n);
     float* part = (float*)ws;
     const int want_bias = dbias != nullptr;
+    if (wgrad_thin_on() && thin_match(g) >= 0) {
+        rc = launch_wgrad_thin_variant(thin_match(g), g, x1, x2, dz, part, want_bias, st, gr.n);
+        if (rc) return rc;
+        return launch_splitk_reduce(part, dw, dbias, (size_t)g->Cout * K, g->Cout, thin_wgrad_splits(g, gr.n), accumulate, gr, st);
+    }
 #define WG(BM_, BN_, WM_, WN_) rc = launch_wgrad<BM_, BN_, WM_, WN_>(g, p, x1, x2, dz, part, M, K, want_bias, st, gr.n)
 #define WGP(BM_, BN_, WM_, WN_) rc = launch_wgrad_pipe<BM_, BN_, WM_, WN_>(g, p, x1, dz, part, M, K, want_bias, st, gr.n)
     if (wgrad_pipe_ok(g, p) && !cg_wgrad_force_legacy) {
@@ -2100,6 +2295,12 @@ extern "C" int cg_conv2d_wgrad_x3_g(const cg_conv_geom* g, const cg_group* group
                                     float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
     return conv2d_wgrad_x3_impl(g, group, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, dw, dbias, accumulate, ws,
                                 ws_bytes, stream, "cg_conv2d_wgrad_x3_g");
+}
+
+extern "C" int cg_conv2d_wgrad_thin(int on) {           // returns the previous setting; workspace queries follow it
+    const int prev = wgrad_thin_on() ? 1 : 0;
+    wgrad_thin_state = on != 0;
+    return prev;
 }
 
 extern "C" int cg_conv2d_fwd_thin(int on) {             // returns the previous setting

@@ -87,6 +87,7 @@ _SIGS = {
     "cg_conv2d_wgrad_legacy": (c_int, [c_int]),
     "cg_conv2d_wgrad_x3_bm256": (c_int, [c_int]),
     "cg_conv2d_fwd_thin": (c_int, [c_int]),
+    "cg_conv2d_wgrad_thin": (c_int, [c_int]),
     "cg_conv2d_dgrad_workspace": (c_size_t, [POINTER(ConvGeom), c_int]),
     "cg_conv2d_dgrad": (c_int, [POINTER(ConvGeom), _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "cg_weight_transpose": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int32), c_int, _P]),
@@ -213,7 +214,7 @@ def workspace(nbytes, slot=0):
     return buf
 
 
-PROF_SLOTS = 180
+PROF_SLOTS = 200
 
 
 def prof_enable(on):

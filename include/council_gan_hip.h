@@ -217,6 +217,9 @@ int cg_conv2d_wgrad_x3_bm256(int on);
  * and the discriminators' 4x4 stride-2 / two-source 3x3 first convolutions, networks.py:44,152,385-386) on the
  * spatial-tile kernel (tile configuration 40 of cg_conv2d_fwd_tile).  Returns the previous setting. */
 int cg_conv2d_fwd_thin(int on);
+/* The same layers' weight (+ bias) gradient on conv_wgrad_thin_kernel (also CG_WGRAD_THIN=1; off by default).  Returns the
+ * previous setting.  Workspace queries follow it. */
+int cg_conv2d_wgrad_thin(int on);
 
 /* Weight re-layout for the data-gradient pass: out[ci - ci0][tc][co] = w[co][tapmap[tc]][ci],
  * ci in [ci0, ci0+nci).  w is [Cout][T][Cin]; out is [nci][Tc][Cout]. */
@@ -317,7 +320,7 @@ int cg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
  * HIP events recorded on the launch stream.  cg_prof_collect() synchronises them and returns, per
  * kernel slot (slot = kernel family * 20 + tile shape * 2 + fast-path flag; see cg_prof_slot_name),
  * launch count, total milliseconds and total algorithmic FLOPs (2*M*N*K of each launch). */
-#define CG_PROF_SLOTS 180
+#define CG_PROF_SLOTS 200
 int cg_prof_enable(int on);
 int cg_prof_collect(int64_t* counts, double* ms, double* flops);
 const char* cg_prof_slot_name(int slot);

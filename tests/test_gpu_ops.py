@@ -476,6 +476,64 @@ def test_thin_input_convolution(cga, case):
         lib.cg_conv2d_fwd_thin(prev)
 
 
+@pytest.mark.parametrize("case", THIN_CASES, ids=[c[0] for c in THIN_CASES])
+def test_thin_input_weight_gradient(cga, case):
+    """conv_wgrad_thin_kernel (cg_conv2d_wgrad_thin) against fp64 and the generic kernel: weight and bias gradient, for one
+    member and for a member-batched launch, overwrite and accumulate."""
+    from ctypes import byref
+    from council_gan_amd import hip, ops
+    _, N, H, W, C1, C2, K, stride, pad, _act = case
+    lib = hip.load()
+    g = torch.Generator().manual_seed(1 + sum(map(ord, case[0])))
+    Ct = C1 + C2
+    x = torch.randn(N, Ct, H, W, generator=g, dtype=torch.float64)
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    gy = torch.randn(N, 64, Ho, Wo, generator=g, dtype=torch.float64) * 1e-2
+    x1d = cl(dev(x[:, :C1]))
+    x2d = cl(dev(x[:, C1:])) if C2 else None
+    gyd = cl(dev(gy))
+    geom = ops.fwd_geom(N, H, W, C1, C2, 0, K, K, stride, pad, 64, 0)
+    nw = 64 * Ct * K * K
+
+    def ref(n0, n1):
+        wz = torch.zeros(64, Ct, K, K, dtype=torch.float64, requires_grad=True)
+        bz = torch.zeros(64, dtype=torch.float64, requires_grad=True)
+        F.conv2d(F.pad(x[n0:n1], (pad,) * 4), wz, bz, stride=stride).backward(gy[n0:n1])
+        return wz.grad, bz.grad
+
+    def run(nmember, accumulate):
+        stride_el = nw + 64 + 32
+        flat = torch.full((nmember * stride_el,), 0.5 if accumulate else float("nan"), device="cuda")
+        grp = hip.Group(nmember, 0, stride_el)
+        wsb = hip.workspace(lib.cg_conv2d_wgrad_workspace_g(byref(geom), byref(grp)))
+        hip.check(lib.cg_conv2d_wgrad_g(byref(geom), byref(grp), hip.ptr(x1d), hip.ptr(x2d), hip.ptr(gyd), hip.ptr(flat[:nw]),
+                                        hip.ptr(flat[nw:]), accumulate, hip.ptr(wsb), wsb.numel(), hip.stream()), "wgrad_g")
+        torch.cuda.synchronize()
+        out = []
+        for m in range(nmember):
+            o = flat[m * stride_el:(m + 1) * stride_el] - (0.5 if accumulate else 0.0)
+            out.append((o[:nw].view(64, K, K, Ct).permute(0, 3, 1, 2).cpu().double(), o[nw:nw + 64].cpu().double()))
+        return out
+
+    members = [1] + ([2] if N % 2 == 0 else [3] if N % 3 == 0 else [])
+    prev = lib.cg_conv2d_wgrad_thin(0)
+    try:
+        base = {n: run(n, 0) for n in members}
+        lib.cg_conv2d_wgrad_thin(1)
+        thin = {n: run(n, 0) for n in members}
+        thin_acc = run(1, 1)
+    finally:
+        lib.cg_conv2d_wgrad_thin(prev)
+    for n in members:
+        per = N // n
+        for m in range(n):
+            rw, rb = ref(m * per, (m + 1) * per)
+            for got in (base[n][m], thin[n][m]):
+                assert rel(got[0], rw) < 5e-6 and rel(got[1], rb) < 5e-6, (n, m, rel(got[0], rw), rel(got[1], rb))
+    rw, rb = ref(0, N)
+    assert rel(thin_acc[0][0], rw) < 2e-5 and rel(thin_acc[0][1], rb) < 2e-5     # (0.5 + g) - 0.5 in fp32
+
+
 # ------------------------------------------------------------------------------------------
 # split-precision (fp16 x 3) kernels: forward, data gradient, weight gradient -- against fp64, with operands whose
 # magnitude is far outside fp16's comfortable range (the device-side power-of-two scale must absorb it)
