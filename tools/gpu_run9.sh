@@ -17,6 +17,8 @@ echo "rc=$? t=$(( $(date +%s) - t0 ))" >> $O/t2_parity.log; tail -3 $O/t2_parity
 # 3. reference fixtures
 timeout -k 5 240 python -m pytest tests/test_gpu_golden.py -m gpu -q -p no:cacheprovider --durations=5 < /dev/null > $O/t3_golden.log 2>&1
 echo "rc=$? t=$(( $(date +%s) - t0 ))" >> $O/t3_golden.log; tail -3 $O/t3_golden.log
+timeout -k 5 90 python -c "import __graft_entry__ as g; g.smoke()" < /dev/null > $O/t3b_smoke.log 2>&1
+echo "smoke rc=$? t=$(( $(date +%s) - t0 ))" >> $O/t3b_smoke.log; tail -2 $O/t3b_smoke.log
 # 4. the opt-in kernels and the C-ABI communicator
 timeout -k 5 120 python -m pytest tests/test_gpu_ops.py tests/test_gpu_world.py -m gpu -q -p no:cacheprovider -k "$NEW" < /dev/null > $O/t4_new.log 2>&1
 echo "rc=$? t=$(( $(date +%s) - t0 ))" >> $O/t4_new.log; tail -4 $O/t4_new.log
@@ -29,11 +31,17 @@ timeout -k 5 120 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-ex
 echo "default: $(grep -o "$J" $O/bench_default.json)"
 CG_FWD_THIN=1 CG_WGRAD_THIN=1 CG_WGRAD_X3_BM256=1 CG_X3_THIN_OUT=20 timeout -k 5 120 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-exact-fp32 --shape-report $O/shapes_optin.txt < /dev/null > $O/bench_optin.json 2> $O/bench_optin.err
 echo "opt-in:  $(grep -o "$J" $O/bench_optin.json)  t=$(( $(date +%s) - t0 ))"
+if [ $(( $(date +%s) - t0 )) -lt 400 ]; then
 CG_FWD_THIN=1 CG_WGRAD_THIN=1 timeout -k 5 100 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-exact-fp32 --no-kernel-profile < /dev/null > $O/bench_thin_only.json 2> $O/bench_thin_only.err
 echo "thin:    $(grep -o "$J" $O/bench_thin_only.json)  t=$(( $(date +%s) - t0 ))"
+fi
 # 7. sharded trainer on one GPU (gloo) -- validated in call 8, transport code touched since
-timeout -k 5 200 python -m pytest tests/test_gpu_world.py -m gpu -q -p no:cacheprovider -k "not single_rank_communicator" < /dev/null > $O/t7_world.log 2>&1
+if [ $(( $(date +%s) - t0 )) -lt 420 ]; then
+timeout -k 5 150 python -m pytest tests/test_gpu_world.py -m gpu -q -p no:cacheprovider -k "not single_rank_communicator" < /dev/null > $O/t7_world.log 2>&1
 echo "rc=$? t=$(( $(date +%s) - t0 ))" >> $O/t7_world.log; tail -2 $O/t7_world.log
+fi
 # 8. HBM traffic / matrix-pipe counters of the wide tile
-timeout -k 5 200 bash tools/pmc_x3w.sh r02_i/pmc_x3w < /dev/null > $O/pmc.log 2>&1
+if [ $(( $(date +%s) - t0 )) -lt 480 ]; then
+timeout -k 5 100 bash tools/pmc_x3w.sh r02_i/pmc_x3w < /dev/null > $O/pmc.log 2>&1
+fi
 cd $GRAFT_REPO_ROOT; tail -5 $O/pmc.log; echo "done t=$(( $(date +%s) - t0 ))"

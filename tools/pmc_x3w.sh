@@ -6,7 +6,7 @@ O=$R/gpurun_out/${1:-pmc_x3w}
 mkdir -p $O
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  timeout -k 5 120 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/$tag -- python $R/tools/prof_x3w.py 16 16 8 > $O/$tag.log 2>&1 < /dev/null
+  timeout -k 5 40 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/$tag -- python $R/tools/prof_x3w.py 16 16 8 > $O/$tag.log 2>&1 < /dev/null
 done
 python - > $O/summary.txt 2>&1 <<PY
 import csv, glob, collections
