@@ -1700,12 +1700,13 @@ int launch_fwd_thin_variant(int v, const cg_conv_geom* g, const float* x1, const
     }
 }
 
-// weight gradient of the thin-input layers (conv_wgrad_thin_kernel): CG_WGRAD_THIN=1 / cg_conv2d_wgrad_thin(1), off by default
+// weight gradient of the thin-input layers (conv_wgrad_thin_kernel): on unless CG_WGRAD_THIN=0 / cg_conv2d_wgrad_thin(0)
+// (1.6 ... 3.3x the generic kernel on the step's shapes, profiles/r02_i_ab_optin.txt)
 static int wgrad_thin_state = -1;
 static bool wgrad_thin_on() {
     if (wgrad_thin_state < 0) {
         const char* e = getenv("CG_WGRAD_THIN");
-        wgrad_thin_state = (e && atoi(e) != 0) ? 1 : 0;
+        wgrad_thin_state = (e && atoi(e) == 0) ? 0 : 1;
     }
     return wgrad_thin_state == 1;
 }
@@ -1815,16 +1816,18 @@ struct WgradPlan {
 // Split plan of ONE member's weight gradient (M = its output rows).  A grouped launch runs the members' identical plans
 // side by side (grid.y), so a member's result does not depend on how many members share the launch; with several members
 // fewer splits per member already fill the chip.
-// CG_WGRAD_X3_BM256=1 (environment, A/B switch, off by default): the split-precision weight gradient of layers with
-// Cout % 256 == 0 and a 128-wide K-tile runs on a 256 x 128 tile / 16 waves (the shape that pays for the forward kernel
-// from two tiles per CU) instead of 128 x 128 / 8 waves.
+// CG_WGRAD_X3_BM256 (environment) / cg_conv2d_wgrad_x3_bm256(): the split-precision weight gradient of layers with
+// Cout % 256 == 0 and a 128-wide K-tile on a 256 x 128 tile / 16 waves (the shape that pays for the forward kernel from
+// two tiles per CU) instead of 128 x 128 / 8 waves.  0 = never, 1 = wherever the layer qualifies, unset / 2 = where it was
+// measured to win (profiles/r02_i_ab_optin.txt: +15...25 % from 64 such tiles over all members, -4 % below).
 static int wgrad_x3_bm256_state = -1;      // -1: not yet read from the environment
-static bool wgrad_x3_bm256() {
+static int wgrad_x3_bm256() {
     if (wgrad_x3_bm256_state < 0) {
         const char* e = getenv("CG_WGRAD_X3_BM256");
-        wgrad_x3_bm256_state = (e && atoi(e) != 0) ? 1 : 0;
+        const int v = e ? atoi(e) : 2;
+        wgrad_x3_bm256_state = (v == 0 || v == 1) ? v : 2;
     }
-    return wgrad_x3_bm256_state == 1;
+    return wgrad_x3_bm256_state;
 }
 
 WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1, bool x3 = false) {
@@ -1848,7 +1851,10 @@ WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1, bool x3 = false) {
         while (p.bn < 128 && p.bn < K) p.bn <<= 1;
         if (p.bn > 128) p.bn = 128;
     }
-    if (x3 && wgrad_x3_bm256() && CG_X3_INTERLEAVE && p.fast && p.bm == 128 && p.bn == 128 && g->Cout % 256 == 0) p.bm = 256;
+    if (x3 && wgrad_x3_bm256() && CG_X3_INTERLEAVE && p.fast && p.bm == 128 && p.bn == 128 && g->Cout % 256 == 0) {
+        const long tiles256 = (long)(g->Cout / 256) * ((K + 127) / 128) * nmember;
+        if (wgrad_x3_bm256() == 1 || tiles256 >= 64) p.bm = 256;
+    }
     p.tiles_m = (g->Cout + p.bm - 1) / p.bm;
     p.tiles_n = (K + p.bn - 1) / p.bn;
     const int slices = (M + 31) / 32;
@@ -2309,9 +2315,9 @@ extern "C" int cg_conv2d_fwd_thin(int on) {             // returns the previous 
     return prev;
 }
 
-extern "C" int cg_conv2d_wgrad_x3_bm256(int on) {      // returns the previous setting; workspace queries follow it
-    const int prev = wgrad_x3_bm256() ? 1 : 0;
-    wgrad_x3_bm256_state = on != 0;
+extern "C" int cg_conv2d_wgrad_x3_bm256(int mode) {    // 0 / 1 / 2 as CG_WGRAD_X3_BM256; returns the previous mode
+    const int prev = wgrad_x3_bm256();
+    wgrad_x3_bm256_state = (mode == 0 || mode == 1) ? mode : 2;
     return prev;
 }
 

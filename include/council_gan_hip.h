@@ -210,15 +210,16 @@ int cg_conv2d_dgrad_g(const cg_conv_geom* g, const cg_group* group, const float*
 
 /* A/B switch: force the non-pipelined weight-gradient kernel (tuning / regression checks only). */
 int cg_conv2d_wgrad_legacy(int on);
-/* A/B switch (also CG_WGRAD_X3_BM256=1 in the environment; off by default): split-precision weight gradients of layers
- * with Cout % 256 == 0 on a 256 x 128 tile / 16 waves.  Returns the previous setting.  Workspace queries follow it. */
-int cg_conv2d_wgrad_x3_bm256(int on);
+/* Split-precision weight gradients of layers with Cout % 256 == 0 on a 256 x 128 tile / 16 waves (also CG_WGRAD_X3_BM256):
+ * 0 = never, 1 = wherever the layer qualifies, 2 (default) = where it was measured to win (>= 64 such tiles over all
+ * members).  Returns the previous mode.  Workspace queries follow it. */
+int cg_conv2d_wgrad_x3_bm256(int mode);
 /* A/B switch (also CG_FWD_THIN=1; off by default): the thin-input layers (3 / 6 / 12 -> 64 channels: the generators' 7x7
  * and the discriminators' 4x4 stride-2 / two-source 3x3 first convolutions, networks.py:44,152,385-386) on the
  * spatial-tile kernel (tile configuration 40 of cg_conv2d_fwd_tile).  Returns the previous setting. */
 int cg_conv2d_fwd_thin(int on);
-/* The same layers' weight (+ bias) gradient on conv_wgrad_thin_kernel (also CG_WGRAD_THIN=1; off by default).  Returns the
- * previous setting.  Workspace queries follow it. */
+/* The same layers' weight (+ bias) gradient on conv_wgrad_thin_kernel (on by default; CG_WGRAD_THIN=0 turns it off).
+ * Returns the previous setting.  Workspace queries follow it. */
 int cg_conv2d_wgrad_thin(int on);
 
 /* Weight re-layout for the data-gradient pass: out[ci - ci0][tc][co] = w[co][tapmap[tc]][ci],

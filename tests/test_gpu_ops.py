@@ -466,7 +466,8 @@ def test_thin_input_convolution(cga, case):
                 ym = torch.full((h, 64, geom.Ho, geom.Wo), float("nan"), device="cuda").contiguous(memory_format=torch.channels_last)
                 xa = x1d[m * h:(m + 1) * h]
                 xb = x2d[m * h:(m + 1) * h] if C2 else None
-                hip.check(lib.cg_conv2d_fwd_tile(byref(gh), hip.ptr(xa), hip.ptr(xb), hip.ptr(cl(dev(wm_))), hip.ptr(dev(bm_)),
+                wmd, bmd = cl(dev(wm_)), dev(bm_)                # (named: a temporary's block may be handed out again at once)
+                hip.check(lib.cg_conv2d_fwd_tile(byref(gh), hip.ptr(xa), hip.ptr(xb), hip.ptr(wmd), hip.ptr(bmd),
                                                  hip.ptr(ym), 40, hip.stream()), "cg_conv2d_fwd_tile")
                 assert torch.equal(yg[m * h:(m + 1) * h], ym)
                 refm = F.conv2d(F.pad(x[m * h:(m + 1) * h], (pad,) * 4), wm_, bm_, stride=stride)
