@@ -229,12 +229,9 @@ def main():
 
     if rank == 0 and world == 1:
         step_tflops = wmin / (ms_per_step / 1000.0)
-        # traffic: HBM bytes per launch of the dominant kernel on its dominant shape (3x3 256->256 @64x64, 70 % of its
-        # launches) from rocprofv3 PMC passes -- 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, profiles/r01_conv_pmc_probe.txt;
-        # the algorithmic bytes of that shape are 36.0e6 (activations 16.8 + weights 2.4 + output 16.8 MB)
         # traffic: not measured inside this run (PMC counters need rocprofv3 passes of their own); the counter-derived
-        # figure for the dominant kernel lives in profiles/ (r01_x3_pmc_v2.txt: 53.3 MB per launch of the 3x3 256->256
-        # @64x64 batch-4 shape vs 36.0 MB algorithmic)
+        # figure for the dominant kernel on its dominant launch is in profiles/r02_i_x3w_pmc.txt (678.7 MB of memory-side
+        # traffic per member-batched res-block launch against 136.6 MB algorithmic)
         roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                 "step_achieved": round(step_tflops, 2),
                 "step_frac": round(step_tflops / (F16X3_PEAK_TFLOPS if trainer._split_fwd else FP32_MFMA_PEAK_TFLOPS), 4),
