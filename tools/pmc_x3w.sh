@@ -1,12 +1,13 @@
 # HBM traffic and matrix-pipe counters of the wide LDS-DMA forward tile (cfg 16) on a member-batched res-block launch.
-# Usage (on the GPU box): bash tools/pmc_x3w.sh [outdir under gpurun_out]   -- three short rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+# Usage (on the GPU box): bash tools/pmc_x3w.sh [outdir under gpurun_out] [tile configuration, default 16; 22 = channel-slice-major K order]   -- three short rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-pmc_x3w}
+CFG=${2:-16}
 mkdir -p $O
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  timeout -k 5 40 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/$tag -- python $R/tools/prof_x3w.py 16 16 8 > $O/$tag.log 2>&1 < /dev/null
+  timeout -k 5 40 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/$tag -- python $R/tools/prof_x3w.py $CFG 16 8 > $O/$tag.log 2>&1 < /dev/null
 done
 python - > $O/summary.txt 2>&1 <<PY
 import csv, glob, collections
