@@ -312,6 +312,15 @@ def main():
                 cb = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
                       "sample": "cpu baseline leg failed: %s: %s" % (type(e).__name__, e)}
             out["cpu_baseline"] = cb
+    if rank == 0 and world > 1:
+        # N > 1: whole-job figures only (the per-kernel HIP-event leg and the CPU baseline belong to the N = 1 line; they
+        # would add collectives outside the timed region for nothing the N = 1 record does not already say)
+        peak = (F16X3_PEAK_TFLOPS if trainer._split_fwd else FP32_MFMA_PEAK_TFLOPS) * world
+        step_tflops = wmin / (ms_per_step / 1000.0)
+        out["roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": round(peak, 1), "traffic": None,
+                           "achieved": round(step_tflops, 2), "frac": round(step_tflops / peak, 4),
+                           "step_note": "W_min of the whole job / step time against %d x the single-GPU peak of the datapath; "
+                                        "per-kernel figures: the N = 1 record" % world}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
