@@ -217,8 +217,9 @@ def main():
                    "forward_precision": ("fp16x3 split-precision MFMA on {hi,lo} fp16 planes, "
                                          "22 significand bits, fp32 accumulate (error below the fp32 kernel's round-off), "
                                          "per-tensor power-of-two scales chosen on the device: every forward, data-gradient "
-                                         "and weight-gradient convolution with >= 32 channels; 3/6-channel first layers and "
-                                         "<= 32-channel heads: fp32 MFMA"
+                                         "and weight-gradient convolution whose contraction operands have a multiple of 32 "
+                                         "channels; the 3/6-channel-input first layers and the gradients of the 3/12-channel "
+                                         "output layers: exact fp32 MFMA"
                                          if trainer._split_fwd else "fp32 MFMA everywhere"),
                    "members_per_launch": (len(trainer._groups[1][0]) if trainer._groups else 1),
                    "execution": ("member-batched: the local members' same layer runs as ONE launch (ops.members, "

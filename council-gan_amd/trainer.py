@@ -14,12 +14,20 @@ What is restructured (results unchanged, SURVEY.md 8d "redundancy the build may 
     identical fake pass per pick, :862-874);
   * D / council-D weight gradients are not computed in gen_update (the reference accumulates and
     then zeroes them);
-  * loss matching (:518-524, 576-586) runs on device rings: no host sync inside the step.
+  * loss matching (:518-524, 576-586) runs on device rings: no host sync inside the step;
+  * the members of a rank run MEMBER-BATCHED: their samples are stacked along the batch, their parameters are slices of
+    one pool per optimizer kind (optim.ParamPool), and every layer / loss / Adam step of the group is one launch
+    (`ops.members`; the reference's sequential member loops, :328,558,747,826,858).  CG_GROUP caps the members per
+    launch (default 4; 1 = member by member);
+  * the discriminator and the council-discriminator update of an iteration touch disjoint networks: they run on two
+    side streams behind a shared prologue (CG_OVERLAP_UPDATES=0 turns that off).
 
 Multi-GPU: one process per GPU, council members sharded across ranks (member m lives on rank
 m // members_per_rank); everything host-side (batch, style noise, Python RNG picks) is replicated;
 the ONLY collective on the data path is one all-gather of the generated images in
-`dis_council_update` (the cross-member dependency at trainer_council.py:853-856, 872-874).
+`dis_council_update` (the cross-member dependency at trainer_council.py:853-856, 872-874).  With more ranks than
+members every member is replicated, each replica takes a slice of the batch and the replicas' flat gradient buffers are
+averaged with one all-reduce per optimizer step (parallel.py).
 """
 import contextlib
 import os
@@ -187,7 +195,8 @@ class Council_Trainer(nn.Module):
         # datapath of the convolutions with >= 32 channels -- forward, data-gradient and weight-gradient, generators and
         # both discriminators: "split" = fp16 x 3 MFMA on {hi, lo} fp16 operand planes (22 significand bits -- error
         # below the fp32 kernel's accumulation round-off -- at 2.5-2.8x its rate; fp32 storage and accumulation),
-        # "fp32" = exact fp32 MFMA everywhere.  The 3/6-channel first layers and the <= 32-channel heads are always fp32.
+        # "fp32" = exact fp32 MFMA everywhere.  Layers whose INPUT has 3 / 6 / 12 channels are always exact fp32 (forward and
+        # weight gradient; so is the data gradient of a 3- / 12-channel OUTPUT layer, whose dz is that thin).
         self._split_fwd = str(hp.get('cg_forward_precision', os.environ.get('CG_FORWARD_PRECISION', 'split'))) == 'split'
 
     # ------------------------------------------------------------------------------------
