@@ -658,12 +658,12 @@ def test_split_precision_weight_gradient_256x128_tile(cga, shape):
             assert rel(wide[n][m][0], base[n][m][0]) < 2e-6
 
 
-# 22-25 (channel-slice-major K order) have not run on a GPU yet: they join the suite with CG_TEST_EXPERIMENTAL=1
+# 22-27 (channel-slice-major K order, 256x64 tile) have not run on a GPU yet: they join the suite with CG_TEST_EXPERIMENTAL=1
 _EXPERIMENTAL = pytest.mark.skipif(os.environ.get("CG_TEST_EXPERIMENTAL") != "1", reason="experimental tile configuration (CG_TEST_EXPERIMENTAL=1)")
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17, 18, 19, 20, 21] +
-                         [pytest.param(c, marks=_EXPERIMENTAL) for c in (22, 23, 24, 25)])
+                         [pytest.param(c, marks=_EXPERIMENTAL) for c in (22, 23, 24, 25, 26, 27)])
 def test_split_precision_forward_every_tile_configuration(cga, cfg):
     """Every tile configuration of conv_fwd_x3_kernel the library ships, forced explicitly, on a shape whose row count
     (960) and channel count (160) are multiples of no tile edge, with bias + LeakyReLU in the epilogue."""
