@@ -1830,6 +1830,17 @@ static int wgrad_x3_bm256() {
     return wgrad_x3_bm256_state;
 }
 
+// CG_WGRAD_X3_WIDE=1 / cg_conv2d_wgrad_x3_wide(1): experimental 256 x 256 LDS-DMA tile (conv_wgrad_x3tw_kernel) for layers
+// with Cout % 256 == 0 and C1 % 256 == 0.  Off by default: not yet run on a GPU.
+static int wgrad_x3_wide_state = -1;
+static bool wgrad_x3_wide() {
+    if (wgrad_x3_wide_state < 0) {
+        const char* e = getenv("CG_WGRAD_X3_WIDE");
+        wgrad_x3_wide_state = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return wgrad_x3_wide_state == 1;
+}
+
 WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1, bool x3 = false) {
     // Every instantiated tile has exactly four 32x32 MFMA wave tiles or more (4 waves / block):
     //   bm=128: bn in {128, 64, 32};  bm=64: bn in {128, 64};  bm=32: bn = 128.
@@ -1854,6 +1865,10 @@ WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1, bool x3 = false) {
     if (x3 && wgrad_x3_bm256() && CG_X3_INTERLEAVE && p.fast && p.bm == 128 && p.bn == 128 && g->Cout % 256 == 0) {
         const long tiles256 = (long)(g->Cout / 256) * ((K + 127) / 128) * nmember;
         if (wgrad_x3_bm256() == 1 || tiles256 >= 64) p.bm = 256;
+    }
+    if (x3 && wgrad_x3_wide() && CG_X3_INTERLEAVE && p.fast && g->Cout % 256 == 0 && Ct % 256 == 0) {
+        p.bm = 256;
+        p.bn = 256;
     }
     p.tiles_m = (g->Cout + p.bm - 1) / p.bm;
     p.tiles_n = (K + p.bn - 1) / p.bn;
@@ -1897,7 +1912,7 @@ bool wgrad_pipe_ok(const cg_conv_geom* g, const WgradPlan& p) {
     if (!p.fast || g->C2 != 0 || (g->Cout & 3)) return false;
     if (ilog2_exact(g->Ho * g->Wo) < 0 || ilog2_exact(g->Wo) < 0) return false;
     if (!((p.bm == 128 && p.bn == 128) || (p.bm == 128 && p.bn == 64) || (p.bm == 64 && p.bn == 64) ||
-          (p.bm == 64 && p.bn == 128) || (p.bm == 256 && p.bn == 128)))     // 256 x 128: split-precision plans only
+          (p.bm == 64 && p.bn == 128) || (p.bm == 256 && p.bn == 128) || (p.bm == 256 && p.bn == 256)))     // 256-row tiles: split-precision plans only
         return false;
     return (size_t)g->N * g->H * g->W * g->C1 * sizeof(float) < (size_t)CG_OOB &&
            (size_t)g->N * g->Ho * g->Wo * g->Cout * sizeof(float) < (size_t)CG_OOB;
@@ -2229,6 +2244,18 @@ int launch_wgrad_x3t(const cg_conv_geom* g, const WgradPlan& p, const void* xs, 
     CG_LAUNCH_CHECK("conv_wgrad_x3t_kernel");
     return CG_OK;
 }
+int launch_wgrad_x3tw(const cg_conv_geom* g, const WgradPlan& p, const void* xs, size_t x_lo, const float* x_scale,
+                      const void* dzs, size_t dz_lo, const float* dz_scale, float* out, int M, int K, int want_bias, hipStream_t st,
+                      int nmember) {
+    dim3 grid(p.tiles_m * p.tiles_n, nmember, p.splits), block(512);
+    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2, dz_plane = (size_t)g->N * g->Ho * g->Wo * g->Cout * 2;
+    ProfScope prof(7, 256, 256, true, 2.0 * (double)M * nmember * (double)g->Cout * (double)K, st, g, nmember);
+    hipLaunchKernelGGL((conv_wgrad_x3tw_kernel<256, 256, 128, 64, 1>), grid, block, 0, st, *g, xs, (unsigned)x3_span(x_lo, x_plane),
+                       x_scale, dzs, (unsigned)x3_span(dz_lo, dz_plane), dz_scale, out, M, K, p.tiles_n, p.slices_per_split,
+                       want_bias, ilog2_exact(g->Ho * g->Wo), ilog2_exact(g->Wo));
+    CG_LAUNCH_CHECK("conv_wgrad_x3tw_kernel");
+    return CG_OK;
+}
 }  // namespace
 #endif
 // CG_WGRAD_X3_PERM=1 in the environment keeps the v_perm / ds_write_b32 loader (A/B against the transposing LDS read)
@@ -2279,6 +2306,8 @@ static int conv2d_wgrad_x3_impl(const cg_conv_geom* g, const cg_group* group, co
 #endif
     if (p.bm == 128 && p.bn == 128) WGX(128, 128, 64, 32);   // 8 waves
 #if CG_X3_INTERLEAVE
+    else if (p.bm == 256 && p.bn == 256)                     // experimental wide tile (CG_WGRAD_X3_WIDE)
+        rc = launch_wgrad_x3tw(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st, gr.n);
     else if (p.bm == 256 && p.bn == 128)                     // 16 waves (CG_WGRAD_X3_BM256), transposing-read kernel only
         rc = launch_wgrad_x3t<256, 128, 64, 32>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st, gr.n);
 #endif
@@ -2301,6 +2330,12 @@ extern "C" int cg_conv2d_wgrad_x3_g(const cg_conv_geom* g, const cg_group* group
                                     float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
     return conv2d_wgrad_x3_impl(g, group, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, dw, dbias, accumulate, ws,
                                 ws_bytes, stream, "cg_conv2d_wgrad_x3_g");
+}
+
+extern "C" int cg_conv2d_wgrad_x3_wide(int on) {        // experimental; returns the previous setting
+    const int prev = wgrad_x3_wide() ? 1 : 0;
+    wgrad_x3_wide_state = on != 0;
+    return prev;
 }
 
 extern "C" int cg_conv2d_wgrad_thin(int on) {           // returns the previous setting; workspace queries follow it

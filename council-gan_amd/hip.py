@@ -86,6 +86,7 @@ _SIGS = {
     "cg_conv2d_wgrad": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "cg_conv2d_wgrad_legacy": (c_int, [c_int]),
     "cg_conv2d_wgrad_x3_bm256": (c_int, [c_int]),
+    "cg_conv2d_wgrad_x3_wide": (c_int, [c_int]),
     "cg_conv2d_fwd_thin": (c_int, [c_int]),
     "cg_conv2d_wgrad_thin": (c_int, [c_int]),
     "cg_conv2d_dgrad_workspace": (c_size_t, [POINTER(ConvGeom), c_int]),

@@ -214,6 +214,9 @@ int cg_conv2d_wgrad_legacy(int on);
  * 0 = never, 1 = wherever the layer qualifies, 2 (default) = where it was measured to win (>= 64 such tiles over all
  * members).  Returns the previous mode.  Workspace queries follow it. */
 int cg_conv2d_wgrad_x3_bm256(int mode);
+/* EXPERIMENTAL (also CG_WGRAD_X3_WIDE=1; off by default, not yet run on a GPU): 256 x 256 LDS-DMA tile of the split-precision
+ * weight gradient for layers with Cout % 256 == 0 and C1 % 256 == 0.  Returns the previous setting. */
+int cg_conv2d_wgrad_x3_wide(int on);
 /* A/B switch (also CG_FWD_THIN=1; off by default): the thin-input layers (3 / 6 / 12 -> 64 channels: the generators' 7x7
  * and the discriminators' 4x4 stride-2 / two-source 3x3 first convolutions, networks.py:44,152,385-386) on the
  * spatial-tile kernel (tile configuration 40 of cg_conv2d_fwd_tile).  Returns the previous setting. */

@@ -11,6 +11,10 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+# kernels / tile configurations written after the round's last GPU call (forward configurations 22-27: channel-slice-major K
+# order, 256x64 tile; the 256x256 weight-gradient tile) have not run on a GPU yet: they join the suite with CG_TEST_EXPERIMENTAL=1
+_EXPERIMENTAL = pytest.mark.skipif(os.environ.get("CG_TEST_EXPERIMENTAL") != "1", reason="experimental kernel (CG_TEST_EXPERIMENTAL=1)")
+
 TOL = 2e-5
 
 
@@ -602,8 +606,22 @@ def test_split_precision_conv_kernels(cga, case):
 @pytest.mark.parametrize("shape", [(4, 16, 16, 256, 256, 3, 1, 1), (6, 9, 16, 128, 512, 4, 2, 1), (3, 8, 8, 512, 256, 1, 1, 0)],
                          ids=["3x3_256to256", "4x4s2_128to512_ragged_rows", "1x1_512to256"])
 def test_split_precision_weight_gradient_256x128_tile(cga, shape):
-    """The opt-in 256 x 128 / 16-wave tile of conv_wgrad_x3t_kernel (cg_conv2d_wgrad_x3_bm256, CG_WGRAD_X3_BM256): against
-    fp64 and against the default 128 x 128 tile, with the bias gradient, for one member and for a member-batched launch."""
+    """The 256 x 128 / 16-wave tile of conv_wgrad_x3t_kernel (cg_conv2d_wgrad_x3_bm256, CG_WGRAD_X3_BM256): against
+    fp64 and against the 128 x 128 tile, with the bias gradient, for one member and for a member-batched launch."""
+    _wgrad_tile_case(cga, shape, lambda lib, on: lib.cg_conv2d_wgrad_x3_bm256(1 if on else 0),
+                     lambda lib, prev: lib.cg_conv2d_wgrad_x3_bm256(prev))
+
+
+@_EXPERIMENTAL
+@pytest.mark.parametrize("shape", [(4, 16, 16, 256, 256, 3, 1, 1), (6, 9, 16, 256, 512, 4, 2, 1), (3, 8, 8, 512, 256, 1, 1, 0)],
+                         ids=["3x3_256to256", "4x4s2_256to512_ragged_rows", "1x1_512to256"])
+def test_split_precision_weight_gradient_wide_tile(cga, shape):
+    """conv_wgrad_x3tw_kernel (256 x 256 LDS-DMA tile, cg_conv2d_wgrad_x3_wide): written after the round's last GPU call."""
+    _wgrad_tile_case(cga, shape, lambda lib, on: lib.cg_conv2d_wgrad_x3_wide(1 if on else 0),
+                     lambda lib, prev: lib.cg_conv2d_wgrad_x3_wide(prev))
+
+
+def _wgrad_tile_case(cga, shape, switch, restore):
     from ctypes import byref
     from council_gan_amd import hip, ops
     N, H, W, Cin, Cout, K, stride, pad = shape
@@ -642,13 +660,13 @@ def test_split_precision_weight_gradient_256x128_tile(cga, shape):
         return out
 
     members = [1] + ([3] if N % 3 == 0 else [2])
-    prev = lib.cg_conv2d_wgrad_x3_bm256(0)
+    prev = switch(lib, False)
     try:
         base = {n: run(n) for n in members}
-        lib.cg_conv2d_wgrad_x3_bm256(1)
+        switch(lib, True)
         wide = {n: run(n) for n in members}
     finally:
-        lib.cg_conv2d_wgrad_x3_bm256(prev)
+        restore(lib, prev)
     for n in members:
         per = N // n
         for m in range(n):
@@ -656,10 +674,6 @@ def test_split_precision_weight_gradient_256x128_tile(cga, shape):
             for got in (base[n][m], wide[n][m]):
                 assert rel(got[0], rw) < 2e-5 and rel(got[1], rb) < 2e-5, (n, m, rel(got[0], rw), rel(got[1], rb))
             assert rel(wide[n][m][0], base[n][m][0]) < 2e-6
-
-
-# 22-27 (channel-slice-major K order, 256x64 tile) have not run on a GPU yet: they join the suite with CG_TEST_EXPERIMENTAL=1
-_EXPERIMENTAL = pytest.mark.skipif(os.environ.get("CG_TEST_EXPERIMENTAL") != "1", reason="experimental tile configuration (CG_TEST_EXPERIMENTAL=1)")
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17, 18, 19, 20, 21] +

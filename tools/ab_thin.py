@@ -112,12 +112,13 @@ def thin_output(lib):
 
 
 def wgrad_256(lib):
-    print("== split-precision weight gradient: 128x128 / 8 waves vs 256x128 / 16 waves (cg_conv2d_wgrad_x3_bm256)")
+    print("== split-precision weight gradient: 128x128 / 8 waves | 256x128 / 16 waves | 256x256 LDS-DMA / 8 waves (experimental), incl. the reduce")
     shapes = [("res 256->256 3x3 @64 b16 (4 members)", 16, 64, 256, 256, 3, 1, 1, 4),
               ("res 256->256 3x3 @64 b4 (1 member)", 4, 64, 256, 256, 3, 1, 1, 1),
               ("128->256 4x4s2 @128 b16 (4 members)", 16, 128, 128, 256, 4, 2, 1, 4),
               ("256->512 4x4s2 @64 b64 (4 members)", 64, 64, 256, 512, 4, 2, 1, 4),
               ("512->512 1x1 @32 b64 (4 members)", 64, 32, 512, 512, 1, 1, 0, 4)]
+    wide_too = "wide" in sys.argv[1:]
     for name, N, HW, Cin, Cout, K, stride, pad, nm in shapes:
         g = ops.fwd_geom(N, HW, HW, Cin, 0, 0, K, K, stride, pad, Cout, 0)
         x = torch.randn(N, Cin, HW, HW, device="cuda").contiguous(memory_format=CL)
@@ -129,8 +130,8 @@ def wgrad_256(lib):
         outs, res = [], []
         with torch.no_grad():
             xs, dzs = ops.split_f16_dynamic(x), ops.split_f16_dynamic(dz)
-            for on in (0, 1):
-                prev = lib.cg_conv2d_wgrad_x3_bm256(on)
+            for label, bm256, wide in (("128x128", 0, 0), ("256x128", 1, 0)) + ((("256x256w", 0, 1),) if wide_too and Cin % 256 == 0 else ()):
+                prev, prevw = lib.cg_conv2d_wgrad_x3_bm256(bm256), lib.cg_conv2d_wgrad_x3_wide(wide)
                 try:
                     flat = torch.zeros(nm * stride_el, device="cuda")
                     wsb = hip.workspace(lib.cg_conv2d_wgrad_workspace_g(byref(g), byref(grp)))
@@ -142,10 +143,11 @@ def wgrad_256(lib):
                     ms = timed(fn, 10)
                 finally:
                     lib.cg_conv2d_wgrad_x3_bm256(prev)
+                    lib.cg_conv2d_wgrad_x3_wide(prevw)
                 outs.append(flat)
-                res.append("%7.1f us %5.1f TF (incl. reduce)" % (ms * 1e3, flops / ms / 1e9))
-        d = float((outs[0] - outs[1]).abs().max() / outs[0].abs().max())
-        print("%-40s | 128x128 %s | 256x128 %s | rel diff %.1e" % (name, res[0], res[1], d), flush=True)
+                res.append("%s %7.1f us %5.1f TF" % (label, ms * 1e3, flops / ms / 1e9))
+        d = max(float((o - outs[0]).abs().max() / outs[0].abs().max()) for o in outs[1:])
+        print("%-40s | %s | max rel diff %.1e" % (name, " | ".join(res), d), flush=True)
 
 
 if __name__ == "__main__":
