@@ -262,7 +262,10 @@ class Council_Trainer(nn.Module):
         # the HBM-bound passes of one hide under the MFMA-bound convolutions of the other.  The caller's stream waits
         # for a side stream at the end of the call that fed it, so anything enqueued afterwards (gen_update, a .item() on
         # a loss) is ordered behind it.  CG_OVERLAP_UPDATES=0 keeps everything on the caller's stream.
-        self._overlap = os.environ.get('CG_OVERLAP_UPDATES', '1') != '0'
+        # (members replicated over several ranks: both updates issue collectives -- the replicas' gradient all-reduce from
+        # either stream, the image all-gather -- on different communicators; until that has run on RCCL the two updates
+        # stay on one stream there unless CG_OVERLAP_UPDATES=1 asks for the overlap)
+        self._overlap = os.environ.get('CG_OVERLAP_UPDATES', '0' if self.shard.dp > 1 else '1') != '0'
         self._side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if self._overlap else []
         self._e0 = None
         n = min(int(os.environ.get('CG_MEMBER_STREAMS', '2')), L)
