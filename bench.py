@@ -10,6 +10,20 @@ N=8: same problem, every member on two GPUs, each taking half of the batch (grad
 the member, council-gan_amd/parallel.py).  images/sec = batch * steps / wall-seconds, wall =
 max over ranks between barrier+synchronize brackets.
 
+Launching.  Under a launcher (WORLD_SIZE / RANK / LOCAL_RANK / MASTER_* in the environment, e.g. the driver's
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) the process is one rank of N.  WITHOUT one,
+`python bench.py --gpus N` (N > 1) starts its N ranks ITSELF: it re-executes this file under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>`, one
+rank per GPU over RCCL, and exits with the launcher's status -- the reference has no multi-process code at all
+(its one cross-member exchange is trainer_council.py:853-856), so the launcher is this repo's job.  Every rank asserts
+`dist.get_world_size() == N`; a mismatch is an error, not a warning.  The N > 1 line carries `rccl_ranks` (the size
+of the communicator the timed steps ran over) and the RCCL version.  N = 8 defaults to BASELINE.json configs[4]'s
+problem (anime2face 256x256, council 8, one member per GPU; its N = 1 denominator is `--cfg 5 --gpus 1`);
+`--replicas` keeps council 4 at N = 8 instead (every member on two GPUs, half a batch each).
+CG_DIST_BACKEND=gloo + CG_SHARE_GPU=1 runs the N ranks on ONE GPU over gloo (tests on a 1-GPU box);
+CG_BENCH_DRY=1 replaces the training step by a no-op and needs no GPU at all (CPU test of the launch /
+rendezvous / timing / reporting protocol, tests/test_host_cpu.py).
+
 Rank 0 prints ONE JSON line; at N=1 it also carries
   "roofline":     dominant kernel (split-precision fp16x3 implicit-GEMM conv) algorithmic TFLOP/s from HIP
                   events on the launch stream vs the peak of the datapath it runs on (fp16 MFMA / 3 passes =
@@ -23,6 +37,8 @@ import copy
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 
@@ -118,6 +134,66 @@ def time_steps(step, fence, warmup, steps, first=0):
     return time.perf_counter() - t0
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: run this file as N ranks under torch.distributed.run (one rank per
+    GPU, rendezvous on 127.0.0.1) and return the launcher's exit status.  Rank 0's JSON line goes to our stdout."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    env["CG_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:      # noqa: BLE001
+        return None
+
+
+def dry_run(args, rank, world):
+    """CG_BENCH_DRY=1: everything bench.py does around the training step -- rank launch, rendezvous, sharding plan,
+    barrier-bracketed timing with the max over ranks, ONE JSON line from rank 0 -- with a no-op step and no GPU.  It is the
+    CPU-testable part of the N > 1 contract; the line says "dry_run": true and its value means nothing."""
+    import council_gan_amd as cga
+    council = args.council if args.council else 4
+    shard = cga.CouncilShard.from_env(council)
+    gathered = shard.gather_scalars([float(m) if m in shard.local else -1.0 for m in range(council)])
+    assert gathered == [float(m) for m in range(council)], gathered
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+    elapsed = time_steps(lambda it: time.sleep(0.001 * (1 + rank)), fence, args.warmup, args.steps)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no training step)", "value": round(args.batch * args.steps / elapsed, 3),
+                          "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True,
+                          "dry_run": True, "ranks": dist.get_world_size() if world > 1 else 1,
+                          "backend": dist.get_backend() if world > 1 else None,
+                          "config": {"workload": "none", "council": council, "members_per_rank": shard.per_rank,
+                                     "replicas_per_member": shard.dp, "local_members_rank0": shard.local}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,7 +210,19 @@ def main():
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32-MFMA sub-record")
     ap.add_argument("--shape-report", default="", help="write the per-layer-shape conv timing table to this file")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N = 8: keep council 4 (every member on two GPUs, half a batch each) instead of council 8")
     args = ap.parse_args()
+    n_req = max(args.gpus, 1)
+    if n_req > 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        # no launcher around us: start the N ranks ourselves (the driver's plain `python bench.py --gpus N`)
+        if os.environ.get("CG_BENCH_SPAWNED"):
+            raise SystemExit("bench.py: spawned as a rank but WORLD_SIZE is not set")
+        raise SystemExit(spawn_ranks(n_req, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != n_req:      # before the rendezvous: a wrong-sized job must not even start
+        raise SystemExit("bench.py: --gpus %d but the launcher started %s rank(s)" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
+    if n_req == 8 and args.cfg == 0 and not args.replicas and not args.council:
+        args.cfg = 5      # 8 GPUs: BASELINE.json configs[4] -- council 8, one member per GPU
     preset = PRESETS.get(args.cfg)
     if preset:
         args.config, args.council, args.batch, args.size = preset["config"], preset["council"], preset["batch"], preset["size"]
@@ -142,11 +230,19 @@ def main():
     import council_gan_amd as cga
     # CG_DIST_BACKEND=gloo + CG_SHARE_GPU=1: several ranks on ONE GPU (smoke test of the N>1 code path on a 1-GPU box)
     backend = os.environ.get("CG_DIST_BACKEND", "nccl")
+    if os.environ.get("CG_BENCH_DRY") == "1":
+        backend = "gloo"
     rank, world, local_rank = cga.init_distributed(backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     if os.environ.get("CG_SHARE_GPU"):
         local_rank = 0
-    if world != max(args.gpus, 1) and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world != n_req or (world > 1 and dist.get_world_size() != n_req):
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    dry = os.environ.get("CG_BENCH_DRY") == "1"
+    if dry:
+        return dry_run(args, rank, world)
+    if world > 1 and not os.environ.get("CG_SHARE_GPU") and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible (CG_SHARE_GPU=1 + CG_DIST_BACKEND=gloo shares one)"
+                         % (world, torch.cuda.device_count()))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -207,6 +303,7 @@ def main():
                    "problem_at_n_gpus": ("same problem at every N (strong scaling): N <= council shards the members, "
                                          "N > council additionally splits every member's batch over N/council replicas; "
                                          "this run: council %d on %d GPU(s)" % (council, world)),
+                   "n1_denominator": "python bench.py --gpus 1" + (" --cfg %d" % args.cfg if args.cfg else ""),
                    "members_per_gpu": council / world if council < world else council // world,
                    "parallelism": ("%d council member(s) per GPU, one all-gather of generated images per iteration"
                                    % (council // world) if world <= council else
@@ -318,6 +415,9 @@ def main():
         # would add collectives outside the timed region for nothing the N = 1 record does not already say)
         peak = (F16X3_PEAK_TFLOPS if trainer._split_fwd else FP32_MFMA_PEAK_TFLOPS) * world
         step_tflops = wmin / (ms_per_step / 1000.0)
+        out["rccl_ranks"] = dist.get_world_size()
+        out["collective_backend"] = dist.get_backend() + (" (native C-ABI communicators)" if trainer.shard.slice_comm is not None else "")
+        out["rccl_version"] = rccl_version() if dist.get_backend() == "nccl" else None
         out["roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": round(peak, 1), "traffic": None,
                            "achieved": round(step_tflops, 2), "frac": round(step_tflops / peak, 4),
                            "step_note": "W_min of the whole job / step time against %d x the single-GPU peak of the datapath; "

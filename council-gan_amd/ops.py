@@ -612,6 +612,10 @@ class SplitWeights:
         self.state = None
         self.views = {}
         self._dgrad = {}
+        # frozen: the mirror was refreshed at the start of an update (Council_Trainer._fresh_mirrors) and must not be
+        # re-split inside it -- with several member groups on several streams, one group's Adam step moves the pool's
+        # version while another group is still reading ITS members' (unchanged) slices of the mirror
+        self.frozen = False
 
     def _storage(self):
         o = self.owner
@@ -625,6 +629,8 @@ class SplitWeights:
         return o.flat['data'], list(zip(o._params, o.flat['offs']))
 
     def refresh(self):
+        if self.frozen and self.version is not None:
+            return True
         st = self._storage()
         if st is None:
             return False

@@ -41,7 +41,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     # -- flat storage ---------------------------------------------------------------------
     def layout(self):
-        """(start offsets, padded total) of the parameters inside this optimizer's flat buffers."""
+        """(sizes, start offsets, padded total) of the parameters inside this optimizer's flat buffers."""
         sizes = [p.numel() for p in self._params]
         # every parameter starts on a 32-ELEMENT boundary of the flat buffers: the fp16 {hi, lo} mirror of the buffer
         # (ops.SplitWeights) interleaves the halves per 32 elements of the flat index, so a tensor's groups must not
@@ -239,12 +239,17 @@ class ParamPool:
         n = len(self.opts) - k0 if n is None else n
         opts = self.opts[k0:k0 + n]
         lead = opts[0]
+        hyper = lambda o: tuple((k, tuple(v) if isinstance(v, (list, tuple)) else v)      # noqa: E731
+                                for k, v in sorted(o.param_groups[0].items()) if k not in ("params", "initial_lr"))
+        same = lockstep and all(o._steps == lead._steps and hyper(o) == hyper(lead) for o in opts[1:])
         if lockstep:
+            # a member-batched launch writes every member's slice but flags only the lead's views.  A member whose own
+            # flags show MORE than the lead's (touched outside a batched launch) keeps them and steps on its own.
             for o in opts[1:]:
                 for p, q in zip(o._params, lead._params):
-                    p._cg_grad._cg_touched = q._cg_grad._cg_touched
-        same = lockstep and all(o._steps == lead._steps and o.param_groups[0]['lr'] == lead.param_groups[0]['lr']
-                                for o in opts[1:])
+                    if p._cg_grad._cg_touched and not q._cg_grad._cg_touched:
+                        same = False
+                    p._cg_grad._cg_touched = p._cg_grad._cg_touched or q._cg_grad._cg_touched
         if not same or n == 1:
             for o in opts:
                 o.step()

@@ -276,16 +276,20 @@ class Council_Trainer(nn.Module):
         """Split this rank's members into runs of consecutive members that execute as one launch.  The largest batched
         tensor (the council discriminator's first full-resolution feature map: (1 + colleagues) * B samples per member,
         dis.dim channels) must stay below 2 GiB -- the kernels address operands with 31-bit byte offsets."""
-        key = tuple(x.shape)
+        hp = self.__dict__.get('_hp_last') or {}
+        n_rel = hp.get('council', {}).get('numberOfCouncil_dis_relative_iteration', 0) if hp else 0
+        key = tuple(x.shape) + (n_rel,)
         if self._groups is not None and self._groups[0] == key:
             return self._groups[1]
         local = self.shard.local
         B, _, H, W = x.shape
-        hp = self.__dict__.get('_hp_last') or {}
-        n_rel = hp.get('council', {}).get('numberOfCouncil_dis_relative_iteration', 0) if hp else 0
         u = min(n_rel, self.council_size - 1) if self.do_dis_council else 0
         width = max(self._nets('dis', self._dirs[0])[local[0]].dim, 64)
         per_member = max((1 + u) * B, 2 * B) * width * H * W * 4
+        if per_member >= (1 << 31):
+            raise hip.HipError("one council member's largest activation (%d samples x %d channels x %dx%d fp32 = %.2f GiB) "
+                               "exceeds the kernels' 31-bit byte offsets: lower batch_size or the image size"
+                               % (max((1 + u) * B, 2 * B), width, H, W, per_member / 2.0 ** 30))
         g = 1
         for cand in range(1, len(local) + 1):
             if len(local) % cand == 0 and cand <= self._group_max and cand * per_member < (1 << 31):
@@ -358,6 +362,21 @@ class Council_Trainer(nn.Module):
         finally:
             dec.split_active = False
 
+    @contextlib.contextmanager
+    def _fresh_mirrors(self, *kinds):
+        """Scope of one update: the {hi, lo} fp16 mirrors of the pools it READS are brought up to date once, on the stream
+        the update starts on (before its member groups fork), and stay as they are until it ends -- a group's optimizer
+        step changes only its own members' weights, which no other group reads (ops.SplitWeights.frozen)."""
+        mgrs = [self._pools[k].split for k in kinds if k in self._pools and self._pools[k].split is not None]
+        for m in mgrs:
+            m.refresh()
+            m.frozen = True
+        try:
+            yield
+        finally:
+            for m in mgrs:
+                m.frozen = False
+
     def _weights_version(self, d, grp):
         opts = [self.gen_opt_s[i] for i in grp]
         gen = self._nets('gen', d)[grp[0]]
@@ -400,7 +419,9 @@ class Council_Trainer(nn.Module):
         if not self._overlap:
             return contextlib.nullcontext(), None
         main = torch.cuda.current_stream()
-        key = tuple(id(x[d]) for d in self._dirs)
+        # the fork mark is valid for THIS batch and THESE generator weights only: a generator step (or a checkpoint load)
+        # after it means the side stream must be ordered behind the caller's stream again (gen_update also clears it)
+        key = tuple(id(x[d]) for d in self._dirs) + (self._pools['gen'].version,)
         side = self._side[k]
         if prologue:
             less = self._hp_last['council']['discriminetro_less_style_by'] if self.do_dis_council else 0
@@ -499,7 +520,7 @@ class Council_Trainer(nn.Module):
         tgt = {'a2b': x['b2a'], 'b2a': x['a2b']}                 # real image of the target domain
         groups = self._plan_groups(x[self._dirs[0]])
         ctx, tok = self._side_stream(0, x, groups, prologue=True)
-        with ctx:
+        with ctx, self._fresh_mirrors('gen', 'dis'):
             pool = self._pools['dis']
             pool.zero_grad()
             s = {}
@@ -564,7 +585,7 @@ class Council_Trainer(nn.Module):
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}
         groups = self._plan_groups(x[self._dirs[0]])
         ctx, tok = self._side_stream(1, x, groups, prologue=False)
-        with ctx:
+        with ctx, self._fresh_mirrors('gen', 'disc'):
             pool = self._pools['disc']
             pool.zero_grad()
             s, s_less = {}, {}
@@ -668,6 +689,7 @@ class Council_Trainer(nn.Module):
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}
         groups = self._plan_groups(x[self._dirs[0]])
         pool = self._pools['gen']
+        self._e0 = None                    # the generators are about to change: no side stream may start from the old mark
         pool.zero_grad()
         s_a = self._style(x_a.size(0))     # both drawn, s_a first (:284-285)
         s_b = self._style(x_b.size(0))
@@ -710,6 +732,8 @@ class Council_Trainer(nn.Module):
                             frozen.append(p)
         s_dev = {}
         n_ring = self._ring_n
+        mirrors = self._fresh_mirrors('gen', 'dis', 'disc')
+        mirrors.__enter__()
         self._fork()
         try:
             for grp in groups:
@@ -784,6 +808,7 @@ class Council_Trainer(nn.Module):
                     pool.step(k0, g, lockstep=g > 1)
         finally:
             self._join()
+            mirrors.__exit__(None, None, None)
             for p in frozen:
                 p.requires_grad_(True)
 
@@ -912,6 +937,8 @@ class Council_Trainer(nn.Module):
 
     def resume(self, checkpoint_dir, hyperparameters):
         dev = self._io_device()
+        self._e0 = None
+        self._enc_cache.clear()
         iterations = 0
         for i in self.shard.local:
             for kind, key in (('gen', 'gen_%d' % i), ('dis', 'dis_%d' % i)) + \

@@ -281,3 +281,41 @@ def test_tool_helpers_on_host(tmp_path):
     TF.save_normalised(torch.linspace(-3, 5, 3 * 4 * 4).view(1, 3, 4, 4), str(tmp_path / "n.png"))
     n = np.asarray(Image.open(tmp_path / "n.png"))
     assert n.shape == (4, 4, 3) and n.min() == 0 and n.max() == 255
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_starts_its_own_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it must start N ranks itself (torch.distributed.run, rendezvous on
+    127.0.0.1) -- the way the driver runs it.  CG_BENCH_DRY=1: everything but the training step, on CPU over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = dict(os.environ, CG_BENCH_DRY="1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                       # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["ranks"] == n and out["steps"] == 2 and out["warmup"] == 1
+    if n == 8:      # 8 GPUs default to BASELINE.json configs[4]: council 8, one member per GPU
+        assert out["config"]["council"] == 8 and out["config"]["members_per_rank"] == 1
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """Under a launcher that started a different number of ranks than --gpus says, bench.py fails instead of measuring
+    the wrong job."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = dict(os.environ, CG_BENCH_DRY="1", WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1", CG_BENCH_SPAWNED="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0
