@@ -1509,6 +1509,39 @@ int validate_geom(const cg_conv_geom* g, const char* who) {
     return CG_OK;
 }
 
+// ---- kernel-selection table (cg_tuning, include/council_gan_hip.h) -------------------------------------------------
+// The ONLY process-wide state of the library: which of several result-equivalent kernels / tile shapes a launch gets.
+// It is read from the CG_* environment ONCE, at the first use, and afterwards changes only through cg_tuning_set()
+// (or the single-field wrappers kept for the A/B tools).  Nothing in it changes what a call computes beyond the last
+// bits; a host that launches from several threads sets it before the first launch.
+static cg_tuning g_tune;
+static std::once_flag g_tune_once;
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static void tuning_from_env() {
+    cg_tuning t{};
+    t.fwd_thin = env_int("CG_FWD_THIN", 0) != 0;
+    t.wgrad_thin = env_int("CG_WGRAD_THIN", 1) != 0;
+    const int bm = env_int("CG_WGRAD_X3_BM256", 2);
+    t.wgrad_x3_bm256 = (bm == 0 || bm == 1) ? bm : 2;
+    t.wgrad_x3_wide = env_int("CG_WGRAD_X3_WIDE", 0) != 0;
+    t.wgrad_x3_perm = getenv("CG_WGRAD_X3_PERM") != nullptr;
+    t.wgrad_legacy = 0;
+    t.x3_wide = env_int("CG_X3_WIDE", 16);
+    const int to = env_int("CG_X3_THIN_OUT", 20);
+    t.x3_thin_out = (to == 20 || to == 21) ? to : 0;
+    t.x3_korder = env_int("CG_X3_KORDER", 0) != 0;
+    t.tile_rows_scale = env_int("CG_TILE_ROWS_SCALE", 1) < 1 ? 1 : env_int("CG_TILE_ROWS_SCALE", 1);
+    t.no_amax_atomic = getenv("CG_NO_AMAX_ATOMIC") != nullptr;
+    g_tune = t;
+}
+static cg_tuning& tune() {
+    std::call_once(g_tune_once, tuning_from_env);
+    return g_tune;
+}
+
 // Per-launch option handed from the C entry point to the launcher that ends up running (set and cleared around one call on
 // the calling thread): where the kernel's epilogue should leave its per-block output maxima, and how many it left.
 struct FwdAmax {
@@ -1520,8 +1553,7 @@ constexpr int CG_AMAX_SLOTS_MAX = 1024;     // == CG_AMAX_MAX_SLOTS of conv_x3.i
 // slots a launch of `blocks` blocks fills (block_amax_store): one each, or 1024 shared ones that must start at zero
 static int amax_slots_for(long blocks, float* state, hipStream_t st) {
     if (blocks <= CG_AMAX_SLOTS_MAX) return (int)blocks;
-    static const bool no_atomic = getenv("CG_NO_AMAX_ATOMIC") != nullptr;      // A/B switch
-    if (no_atomic) return 0;
+    if (tune().no_amax_atomic) return 0;      // A/B switch
     (void)hipMemsetAsync(state + 2, 0, CG_AMAX_SLOTS_MAX * sizeof(float), st);
     return CG_AMAX_SLOTS_MAX;
 }
@@ -1639,14 +1671,7 @@ bool pipe_ok(const cg_conv_geom* g, int K) {
 // ---- thin-input layers (conv_fwd_thin_kernel) -----------------------------------------------------------------------
 // CG_FWD_THIN=1 in the environment / cg_conv2d_fwd_thin(1): layers that match a compiled (KH, KW, channels, stride) variant
 // run on the spatial-tile kernel (tile configuration 40); off by default until measured in the step.
-static int fwd_thin_state = -1;
-static bool fwd_thin_on() {
-    if (fwd_thin_state < 0) {
-        const char* e = getenv("CG_FWD_THIN");
-        fwd_thin_state = (e && atoi(e) != 0) ? 1 : 0;
-    }
-    return fwd_thin_state == 1;
-}
+static bool fwd_thin_on() { return tune().fwd_thin != 0; }
 
 struct ThinVariant { int kh, kw, ct, s; };
 static const ThinVariant thin_variants[] = {{7, 7, 3, 1}, {4, 4, 3, 2}, {3, 3, 6, 1}, {3, 3, 3, 1}, {1, 1, 12, 1}};
@@ -1702,14 +1727,7 @@ int launch_fwd_thin_variant(int v, const cg_conv_geom* g, const float* x1, const
 
 // weight gradient of the thin-input layers (conv_wgrad_thin_kernel): on unless CG_WGRAD_THIN=0 / cg_conv2d_wgrad_thin(0)
 // (1.6 ... 3.3x the generic kernel on the step's shapes, profiles/r02_i_ab_optin.txt)
-static int wgrad_thin_state = -1;
-static bool wgrad_thin_on() {
-    if (wgrad_thin_state < 0) {
-        const char* e = getenv("CG_WGRAD_THIN");
-        wgrad_thin_state = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return wgrad_thin_state == 1;
-}
+static bool wgrad_thin_on() { return tune().wgrad_thin != 0; }
 // blocks (= splits) per member of a thin weight-gradient launch; M = rows of one member
 static int thin_wgrad_splits(const cg_conv_geom* g, int nmember) {
     const int imgs = g->N / nmember;
@@ -1789,6 +1807,7 @@ int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float*
 // fewer tiles fill the 256 CUs better with 64x64 tiles (two LDS stages when very few tiles).  M = rows of the LAUNCH.
 int pick_fwd_cfg(const cg_conv_geom* g, long M, bool pipe) {
     if (fwd_thin_on() && thin_match(g) >= 0) return 40;
+    M *= tune().tile_rows_scale;      // test hook: choose tiles as if the launch had k x the rows (cg_tuning.tile_rows_scale)
     const long blocks128 = ((M + 127) / 128) * ((g->Cout + 127) / 128);
     if (g->Cout > 64) {
         if (blocks128 >= 192) return pipe ? 20 : 6;
@@ -1805,7 +1824,7 @@ int pick_fwd_cfg(const cg_conv_geom* g, long M, bool pipe) {
     return 2;
 }
 
-bool cg_wgrad_force_legacy = false;  // A/B switch (cg_conv2d_wgrad_legacy)
+static bool wgrad_force_legacy() { return tune().wgrad_legacy != 0; }  // A/B switch (cg_conv2d_wgrad_legacy)
 
 struct WgradPlan {
     int bm, bn;
@@ -1820,26 +1839,11 @@ struct WgradPlan {
 // Cout % 256 == 0 and a 128-wide K-tile on a 256 x 128 tile / 16 waves (the shape that pays for the forward kernel from
 // two tiles per CU) instead of 128 x 128 / 8 waves.  0 = never, 1 = wherever the layer qualifies, unset / 2 = where it was
 // measured to win (profiles/r02_i_ab_optin.txt: +15...25 % from 64 such tiles over all members, -4 % below).
-static int wgrad_x3_bm256_state = -1;      // -1: not yet read from the environment
-static int wgrad_x3_bm256() {
-    if (wgrad_x3_bm256_state < 0) {
-        const char* e = getenv("CG_WGRAD_X3_BM256");
-        const int v = e ? atoi(e) : 2;
-        wgrad_x3_bm256_state = (v == 0 || v == 1) ? v : 2;
-    }
-    return wgrad_x3_bm256_state;
-}
+static int wgrad_x3_bm256() { return tune().wgrad_x3_bm256; }
 
 // CG_WGRAD_X3_WIDE=1 / cg_conv2d_wgrad_x3_wide(1): experimental 256 x 256 LDS-DMA tile (conv_wgrad_x3tw_kernel) for layers
 // with Cout % 256 == 0 and C1 % 256 == 0.  Off by default: not yet run on a GPU.
-static int wgrad_x3_wide_state = -1;
-static bool wgrad_x3_wide() {
-    if (wgrad_x3_wide_state < 0) {
-        const char* e = getenv("CG_WGRAD_X3_WIDE");
-        wgrad_x3_wide_state = (e && atoi(e) != 0) ? 1 : 0;
-    }
-    return wgrad_x3_wide_state == 1;
-}
+static bool wgrad_x3_wide() { return tune().wgrad_x3_wide != 0; }
 
 WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1, bool x3 = false) {
     // Every instantiated tile has exactly four 32x32 MFMA wave tiles or more (4 waves / block):
@@ -2065,7 +2069,7 @@ static int conv2d_fwd_x3_impl(const cg_conv_geom* g, const cg_group* group, cons
     fill_class(b.c[0], g, (const float*)ws, gr.n);
     b.c[0].w_bytes = (unsigned)(w_lo_elems * 2);
     b.c[0].pad_ = (int32_t)w_span;
-    const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, (long)Mm * gr.n, g->C1) : tile_cfg;
+    const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, (long)Mm * gr.n, g->C1, g->T) : tile_cfg;
     CG_CHECK_ARG((cfg != 6 && cfg != 7) || g->C1 % 64 == 0, "%s: tile configuration %d needs C %% 64 == 0", who, cfg);
     const int bm = x3_cfg_bm(cfg);
     double* st_ptr = nullptr;
@@ -2181,7 +2185,7 @@ static int conv2d_wgrad_impl(const cg_conv_geom* g, const cg_group* group, const
     }
 #define WG(BM_, BN_, WM_, WN_) rc = launch_wgrad<BM_, BN_, WM_, WN_>(g, p, x1, x2, dz, part, M, K, want_bias, st, gr.n)
 #define WGP(BM_, BN_, WM_, WN_) rc = launch_wgrad_pipe<BM_, BN_, WM_, WN_>(g, p, x1, dz, part, M, K, want_bias, st, gr.n)
-    if (wgrad_pipe_ok(g, p) && !cg_wgrad_force_legacy) {
+    if (wgrad_pipe_ok(g, p) && !wgrad_force_legacy()) {
         if (p.bm == 128 && p.bn == 128) WGP(128, 128, 64, 32);   // 8 waves
         else if (p.bm == 128 && p.bn == 64) WGP(128, 64, 64, 32);
         else if (p.bm == 64 && p.bn == 64) WGP(64, 64, 32, 32);
@@ -2259,10 +2263,7 @@ int launch_wgrad_x3tw(const cg_conv_geom* g, const WgradPlan& p, const void* xs,
 }  // namespace
 #endif
 // CG_WGRAD_X3_PERM=1 in the environment keeps the v_perm / ds_write_b32 loader (A/B against the transposing LDS read)
-static bool wgrad_x3_use_tr() {
-    static const bool on = CG_X3_INTERLEAVE && getenv("CG_WGRAD_X3_PERM") == nullptr;
-    return on;
-}
+static bool wgrad_x3_use_tr() { return CG_X3_INTERLEAVE && !tune().wgrad_x3_perm; }
 
 static int wgrad_x3_ok(const cg_conv_geom* g, int nmember) {
     if (!g || g->T < 1 || g->T > CG_MAX_TAPS || nmember < 1 || g->N % nmember) return 0;
@@ -2332,32 +2333,44 @@ extern "C" int cg_conv2d_wgrad_x3_g(const cg_conv_geom* g, const cg_group* group
                                 ws_bytes, stream, "cg_conv2d_wgrad_x3_g");
 }
 
-extern "C" int cg_conv2d_wgrad_x3_wide(int on) {        // experimental; returns the previous setting
-    const int prev = wgrad_x3_wide() ? 1 : 0;
-    wgrad_x3_wide_state = on != 0;
+// ---- the kernel-selection table behind the ABI (see cg_tuning above) ------------------------------------------------------
+extern "C" int cg_tuning_get(cg_tuning* out) {
+    CG_CHECK_ARG(out != nullptr, "cg_tuning_get: null pointer");
+    *out = tune();
+    return CG_OK;
+}
+extern "C" int cg_tuning_set(const cg_tuning* in) {
+    CG_CHECK_ARG(in != nullptr, "cg_tuning_set: null pointer");
+    CG_CHECK_ARG(in->wgrad_x3_bm256 >= 0 && in->wgrad_x3_bm256 <= 2 && in->tile_rows_scale >= 1 && in->tile_rows_scale <= 64 &&
+                     (in->x3_thin_out == 0 || in->x3_thin_out == 20 || in->x3_thin_out == 21) &&
+                     (in->x3_wide == 0 || in->x3_wide == 1 || in->x3_wide == 16 || in->x3_wide == 17),
+                 "cg_tuning_set: field out of range");
+    tune() = *in;
+    return CG_OK;
+}
+// single-field wrappers (A/B tools and tests); each returns the previous setting
+extern "C" int cg_conv2d_wgrad_x3_wide(int on) {        // experimental
+    const int prev = tune().wgrad_x3_wide;
+    tune().wgrad_x3_wide = on != 0;
     return prev;
 }
-
-extern "C" int cg_conv2d_wgrad_thin(int on) {           // returns the previous setting; workspace queries follow it
-    const int prev = wgrad_thin_on() ? 1 : 0;
-    wgrad_thin_state = on != 0;
+extern "C" int cg_conv2d_wgrad_thin(int on) {           // workspace queries follow it
+    const int prev = tune().wgrad_thin;
+    tune().wgrad_thin = on != 0;
     return prev;
 }
-
-extern "C" int cg_conv2d_fwd_thin(int on) {             // returns the previous setting
-    const int prev = fwd_thin_on() ? 1 : 0;
-    fwd_thin_state = on != 0;
+extern "C" int cg_conv2d_fwd_thin(int on) {
+    const int prev = tune().fwd_thin;
+    tune().fwd_thin = on != 0;
     return prev;
 }
-
-extern "C" int cg_conv2d_wgrad_x3_bm256(int mode) {    // 0 / 1 / 2 as CG_WGRAD_X3_BM256; returns the previous mode
-    const int prev = wgrad_x3_bm256();
-    wgrad_x3_bm256_state = (mode == 0 || mode == 1) ? mode : 2;
+extern "C" int cg_conv2d_wgrad_x3_bm256(int mode) {    // 0 / 1 / 2 as CG_WGRAD_X3_BM256
+    const int prev = tune().wgrad_x3_bm256;
+    tune().wgrad_x3_bm256 = (mode == 0 || mode == 1) ? mode : 2;
     return prev;
 }
-
 extern "C" int cg_conv2d_wgrad_legacy(int on) {
-    cg_wgrad_force_legacy = on != 0;
+    tune().wgrad_legacy = on != 0;
     return CG_OK;
 }
 
@@ -2615,7 +2628,7 @@ extern "C" int cg_conv2d_dgrad_x3_run(const cg_conv_geom* g, const cg_group* gro
     X3Extra ex;
     ex.w_scale_dev = w_scale_dev;
     ex.mb = Members{gr.n, 0, (long long)wt_elems * 4, 0};
-    return launch_x3_cfg(pick_x3_cfg(nci, m_total, g->Cout), b, p.ncls, dz_split, nullptr, dx, (unsigned)(dz_lo_elems * 2),
+    return launch_x3_cfg(pick_x3_cfg(nci, m_total, g->Cout, p.cg[0].T), b, p.ncls, dz_split, nullptr, dx, (unsigned)(dz_lo_elems * 2),
                          (unsigned)x3_span(dz_lo_elems, dz_plane), 1.0f / w_scale, dz_scale_dev, cg_s(stream), nullptr, nullptr, 0,
                          ex);
 }

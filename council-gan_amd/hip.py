@@ -31,6 +31,13 @@ class Group(ctypes.Structure):
     _fields_ = [("n", c_int32), ("reserved", c_int32), ("stride", c_int64)]
 
 
+class Tuning(ctypes.Structure):
+    """cg_tuning: the library's kernel-selection table (its only process-wide state)."""
+    _fields_ = [(n, c_int32) for n in ("fwd_thin", "wgrad_thin", "wgrad_x3_bm256", "wgrad_x3_wide", "wgrad_x3_perm",
+                                       "wgrad_legacy", "x3_wide", "x3_thin_out", "x3_korder", "tile_rows_scale",
+                                       "no_amax_atomic")] + [("reserved", c_int32 * 5)]
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -84,6 +91,8 @@ _SIGS = {
     "cg_conv2d_fwd_tile": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P]),
     "cg_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvGeom)]),
     "cg_conv2d_wgrad": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "cg_tuning_get": (c_int, [POINTER(Tuning)]),
+    "cg_tuning_set": (c_int, [POINTER(Tuning)]),
     "cg_conv2d_wgrad_legacy": (c_int, [c_int]),
     "cg_conv2d_wgrad_x3_bm256": (c_int, [c_int]),
     "cg_conv2d_wgrad_x3_wide": (c_int, [c_int]),
@@ -213,6 +222,34 @@ def workspace(nbytes, slot=0):
         buf = torch.empty(n, dtype=torch.uint8, device="cuda")
         _ws_cache[dev] = buf
     return buf
+
+
+def tuning():
+    """Current kernel-selection table (cg_tuning_get)."""
+    t = Tuning()
+    check(load().cg_tuning_get(ctypes.byref(t)), "cg_tuning_get")
+    return t
+
+
+class tuned:
+    """`with hip.tuned(x3_korder=1, tile_rows_scale=4): ...` -- cg_tuning fields for a scope (tests / A-B tools)."""
+
+    def __init__(self, **fields):
+        self.fields = fields
+
+    def __enter__(self):
+        self.prev = tuning()
+        t = tuning()
+        for k, v in self.fields.items():
+            if k not in dict(Tuning._fields_):
+                raise AttributeError("cg_tuning has no field %r" % k)
+            setattr(t, k, int(v))
+        check(load().cg_tuning_set(ctypes.byref(t)), "cg_tuning_set")
+        return t
+
+    def __exit__(self, *exc):
+        check(load().cg_tuning_set(ctypes.byref(self.prev)), "cg_tuning_set")
+        return False
 
 
 PROF_SLOTS = 200

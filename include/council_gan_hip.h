@@ -11,7 +11,12 @@
  *     NCHW shape), dense; weights are physically [Cout][KH][KW][Cin] (channels_last OIHW);
  *   - raw device pointers + explicit sizes, no torch types; the caller (PyTorch's caching
  *     allocator) owns every buffer including workspaces;
- *   - kernels are enqueued on `stream` and never synchronise; no global mutable state;
+ *   - kernels are enqueued on `stream` and never synchronise.  The data path has no global mutable state: what a
+ *     call computes depends on its arguments only, and calls are reentrant per stream (per-launch side channels
+ *     are thread-local and live for one call).  The ONE piece of process-wide state is the kernel-selection table
+ *     `cg_tuning` below -- which of several result-equivalent kernels / tile shapes a launch gets -- read from the
+ *     CG_* environment once, at first use, and changed only through cg_tuning_set(); plus the opt-in per-launch
+ *     timing table of cg_prof_enable (measurement only) and the RCCL communicator handles the caller owns;
  *   - return value 0 = ok, negative = error (see cg_last_error()); nothing throws across the ABI.
  */
 #ifndef COUNCIL_GAN_HIP_H
@@ -208,6 +213,30 @@ size_t cg_conv2d_dgrad_workspace_g(const cg_conv_geom* g, const cg_group* group,
 int cg_conv2d_dgrad_g(const cg_conv_geom* g, const cg_group* group, const float* dz, const float* w, int ci0, int nci,
                       float* dx, void* ws, size_t ws_bytes, cg_stream_t stream);
 
+/* Kernel-selection table: the library's only process-wide state (see "Conventions").  Every field selects among
+ * kernels / tile shapes whose results agree to the last bits (fp32 datapath: bit for bit); none changes what a call
+ * means.  Defaults come from the environment variable named with each field, read once at the first use of the library.
+ * A multi-threaded host sets the table before its first launch.  There is no reference counterpart (the reference
+ * leaves algorithm choice to cuDNN, train.py:61 `cudnn.deterministic`). */
+typedef struct cg_tuning {
+    int32_t fwd_thin;        /* CG_FWD_THIN (0): thin-input first layers on the spatial-tile kernel */
+    int32_t wgrad_thin;      /* CG_WGRAD_THIN (1): their weight gradient on conv_wgrad_thin_kernel */
+    int32_t wgrad_x3_bm256;  /* CG_WGRAD_X3_BM256 (2): 256 x 128 weight-gradient tile: 0 never, 1 always, 2 where measured to win */
+    int32_t wgrad_x3_wide;   /* CG_WGRAD_X3_WIDE (0): 256 x 256 LDS-DMA weight-gradient tile */
+    int32_t wgrad_x3_perm;   /* CG_WGRAD_X3_PERM (0): v_perm loader instead of the transposing LDS read */
+    int32_t wgrad_legacy;    /* (0): non-pipelined fp32 weight-gradient kernel */
+    int32_t x3_wide;         /* CG_X3_WIDE (16): wide LDS-DMA forward tile: 0 never, 16 256x256 where it wins, 17 256x128, 1 both */
+    int32_t x3_thin_out;     /* CG_X3_THIN_OUT (20): tile for <= 32 output channels: 0 off, 20 = 128x32, 21 = 256x32 */
+    int32_t x3_korder;       /* CG_X3_KORDER (0): channel-slice-major K order of the split-precision forward / data-gradient tiles */
+    int32_t tile_rows_scale; /* CG_TILE_ROWS_SCALE (1): TEST HOOK -- choose tiles as if a launch had k x its rows, so that a
+                              * batch-1 parity run exercises the tiles the batch-k benchmark selects */
+    int32_t no_amax_atomic;  /* CG_NO_AMAX_ATOMIC (0): launches with > 1024 blocks do not report output maxima */
+    int32_t reserved[5];
+} cg_tuning;
+int cg_tuning_get(cg_tuning* out);
+int cg_tuning_set(const cg_tuning* in);
+
+/* Single-field wrappers over cg_tuning kept for the A/B tools; each returns the previous setting. */
 /* A/B switch: force the non-pipelined weight-gradient kernel (tuning / regression checks only). */
 int cg_conv2d_wgrad_legacy(int on);
 /* Split-precision weight gradients of layers with Cout % 256 == 0 on a 256 x 128 tile / 16 waves (also CG_WGRAD_X3_BM256):

@@ -612,7 +612,6 @@ def test_split_precision_weight_gradient_256x128_tile(cga, shape):
                      lambda lib, prev: lib.cg_conv2d_wgrad_x3_bm256(prev))
 
 
-@_EXPERIMENTAL
 @pytest.mark.parametrize("shape", [(4, 16, 16, 256, 256, 3, 1, 1), (6, 9, 16, 256, 512, 4, 2, 1), (3, 8, 8, 512, 256, 1, 1, 0)],
                          ids=["3x3_256to256", "4x4s2_256to512_ragged_rows", "1x1_512to256"])
 def test_split_precision_weight_gradient_wide_tile(cga, shape):
@@ -676,8 +675,7 @@ def _wgrad_tile_case(cga, shape, switch, restore):
             assert rel(wide[n][m][0], base[n][m][0]) < 2e-6
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17, 18, 19, 20, 21] +
-                         [pytest.param(c, marks=_EXPERIMENTAL) for c in (22, 23, 24, 25, 26, 27)])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27])
 def test_split_precision_forward_every_tile_configuration(cga, cfg):
     """Every tile configuration of conv_fwd_x3_kernel the library ships, forced explicitly, on a shape whose row count
     (960) and channel count (160) are multiples of no tile edge, with bias + LeakyReLU in the epilogue."""

@@ -50,13 +50,26 @@ def _cfg(name, council, iteration=60000):
 
 @pytest.mark.slow
 def test_bench_shape_iteration_vs_oracle(cga):
-    """BASELINE.json configs[2] / bench.py's default workload at batch 1: every x3 / pipelined tile configuration the
-    bench uses at 256x256 with 64..512 channels, all four members, council + focus losses live."""
+    """BASELINE.json configs[2] / bench.py's default workload at batch 1 ON THE BENCH'S TILES: the library chooses tile
+    shapes from the rows of a launch, and batch 1 has a quarter of the benchmark's (batch 4), so the tile heuristics are
+    told to plan for 4 x the rows (cg_tuning.tile_rows_scale, a test hook) -- every convolution then runs the very kernel
+    the benchmark runs for that layer (the 256x256 LDS-DMA tile on the res-block shape, the 256x128 tiles, the 256x128
+    weight-gradient tile), all four members, council + focus losses live."""
     cfg = _cfg("male2female_council_folder.yaml", 4)
     tr_probe = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
     assert tr_probe._split_fwd, "the benchmarked datapath is the split-precision one"
     del tr_probe
-    P.iteration_vs_oracle(cga, cfg, 256, 1, seed=1, report="cfg3 256^2 council 4 B1")
+    cga.hip.prof_enable(True)
+    try:
+        with cga.hip.tuned(tile_rows_scale=4):
+            P.iteration_vs_oracle(cga, cfg, 256, 1, seed=1, report="cfg3 256^2 council 4 B1, bench tiles")
+        torch.cuda.synchronize()
+        ran = cga.hip.prof_collect()
+    finally:
+        cga.hip.prof_enable(False)
+    print("[bench tiles] kernels of the iteration:", sorted(ran))
+    assert any(k.startswith("conv_fwd_x3w_kernel<256,256") for k in ran), sorted(ran)        # the dominant kernel of the bench
+    assert any(k.startswith("conv_wgrad_x3t_kernel<256,128") for k in ran), sorted(ran)
 
 
 def test_cfg2_iteration_vs_oracle(cga):
