@@ -145,11 +145,11 @@ class OracleGen:
         return widths
 
     def mlp(self, style):
-        """networks.py:432-443: Linear-ReLU, (n_blk-2) x Linear-ReLU, Linear."""
+        """networks.py:432-443: Linear-activ, (n_blk-2) x Linear-activ, Linear (activ = gen.activ, networks.py:251-254)."""
         sd = self.sd
         h = style.view(style.size(0), -1)
-        h = F.relu(F.linear(h, sd['mlp.model.0.fc.weight'], sd['mlp.model.0.fc.bias']))
-        h = F.relu(F.linear(h, sd['mlp.model.1.fc.weight'], sd['mlp.model.1.fc.bias']))
+        h = _act(F.linear(h, sd['mlp.model.0.fc.weight'], sd['mlp.model.0.fc.bias']), self.activ)
+        h = _act(F.linear(h, sd['mlp.model.1.fc.weight'], sd['mlp.model.1.fc.bias']), self.activ)
         return F.linear(h, sd['mlp.model.2.fc.weight'], sd['mlp.model.2.fc.bias'])
 
     # networks.py:285-301 + Decoder_V2_atten networks.py:374-415

@@ -4,9 +4,10 @@ Criteria (north star: within 1e-3 rel-fp32):
   * every loss <= 1e-3 relative to the fp32 oracle, except the mask_zero_one criterion (mean 1/(|m-c|+eps): it amplifies
     a mask perturbation by up to 1/eps^2), which is judged like the generator gradients;
   * discriminator / council-discriminator gradients: l2-rel error against the fp64 oracle <= 1e-3;
-  * generator gradients: the reference's own fp32-vs-fp64 gradient gap is 2-4e-3 and chaotic in the
-    forward round-off; judged by level (within the measured chaos band of the reference arithmetic itself) AND per-tensor
-    uniformity of the error -- see GEN_GRAD_FACTOR / check_gen_grad below;
+  * generator gradients: the reference's own fp32-vs-fp64 gradient gap is 2-4e-3 -- flip noise of
+    ReLU sign decisions, a lottery in the forward round-off; judged by level (an absolute cap of 1e-2) AND per-tensor
+    uniformity of the error -- see GEN_GRAD_CAP / check_gen_grad below; the backward kernels themselves are pinned
+    tensor by tensor at 1e-3 by the smooth-network test (tests/test_gpu_parity_targets.py);
   * post-Adam weights: mean |w_ours - w_fp64| <= max(2 x mean |w_fp32 - w_fp64|, 2e-6) per network (one Adam step moves
     every weight by ~lr = 1e-4 in the direction of its gradient's sign, so round-off-sized gradients flip steps in the
     reference too)."""
@@ -19,36 +20,55 @@ import torch
 from oracle import council_oracle as O
 
 ACT_TOL = 1e-3
-# Generator gradients.  The error of ANY fp32 evaluation against fp64 is a single global perturbation born at the loss
-# head (the mask criteria 1/(|m - c| + eps), the steep tanh(10 x) mask, ReLU / LeakyReLU sign decisions): every tensor of a
-# generator carries the SAME relative error (tools/diag_gengrad.py, profiles/r02_gengrad_diag.txt: e.g. 2.9e-3 +- 3 % over
-# all 60 tensors), and its size is CHAOTIC in the forward round-off, not a property of the backward arithmetic: re-running
-# the reference arithmetic itself (the fp32 oracle, same ATen kernels) with every Conv2dBlock output perturbed by a relative
-# 6e-7 -- one extra rounding -- moves that error by 0.8x ... 18x, member by member (tools/diag_gengrad_lottery.py,
-# profiles/r02_gengrad_lottery.txt: median 2.4x, 90th percentile 13x on anime2face 128^2).  The HIP path's forward round-off
-# is ~2x the CPU's (sequential MFMA accumulation along K; profiles/r02_forward_error.txt), i.e. such a perturbation.  Hence:
-#   (1) level:      err(ours, fp64) <= max(GEN_GRAD_FACTOR x err(fp32 oracle, fp64), 1e-3), factor 20 = the chaos band;
-#   (2) uniformity: once the error is in the chaotic regime (> 1e-3), no tensor that carries >= 2 % of the gradient norm
-#                   has a relative error above 3 x the overall one -- a wrong backward kernel shows up in ITS tensors,
-#                   not as a global scale (this is the check that discriminates; the discriminator gradients pin the same
-#                   kernels at 1e-7).  Tensors next to the loss head sit BELOW the common level, which is fine.
-GEN_GRAD_FACTOR = 20.0
+# Generator gradients.  What separates two fp32-class evaluations of a generator gradient is a handful of DISCRETE events:
+# ReLU sign decisions on pre-activations that are zero to within the forward round-off.  Each flipped element switches its
+# whole upstream contribution on or off, so the gradient error against fp64 is Poisson "flip noise", the same relative size
+# on every tensor upstream of the flipped layers and ~ sqrt(forward round-off x elements) in size:
+#   * the discriminators (5 M activations, round-off 1e-7) expect < 1 flip per iteration: their gradients agree to 1e-7;
+#   * the generators (281 M activations per forward at config 3) see ~10 flips on the CPU reference (round-off 1e-7:
+#     measured 1.5e-4 ... 2e-3 l2-rel), a few times more on sequential fp32 MFMA accumulation, and
+#     ~20 x more on the 22-bit split-precision operands (round-off 2e-6 on cancelling sums) -- sqrt(20) ~ 4.5 x the error;
+#   * with smooth activations (tanh instead of ReLU) the SAME kernels agree with fp64 to 1e-5 on every tensor
+#     (tools/diag_smooth.py, profiles/r03_smooth_backward.txt; test_generator_backward_chain_smooth_loss[tanh]) -- the
+#     backward arithmetic is not where the difference comes from; swapping the split-precision backward kernels for the
+#     exact-fp32 ones leaves the error unchanged to three digits: it is decided in the forward pass;
+#   * which elements flip is a lottery: re-running the reference arithmetic itself with every Conv2dBlock output perturbed
+#     by a relative 6e-7 moves its error by 0.8x ... 18x member by member (profiles/r02_gengrad_lottery.txt).
+# Hence, per generator and iteration:
+#   (1) level:      err(ours, fp64) <= max(GEN_GRAD_CAP = 1e-2, GEN_GRAD_FACTOR = 5 x err(fp32 oracle, fp64)) -- an absolute
+#                   cap of 1 % of the gradient norm; the factor (sqrt of the round-off ratio) only matters where the
+#                   reference's own draw is above 2e-3.  (Round 2 used 20 x the oracle's error with no cap: up to 8 %.)
+#   (2) uniformity: no tensor with a non-negligible gradient (>= 1e-4 of the total norm: every weight, every live bias)
+#                   has a relative error above 3 x the overall one once that is above 1e-3 -- flip noise is common to all
+#                   tensors upstream of the flips, a wrong backward kernel shows up in ITS tensors.
+# What pins the backward kernels tensor by tensor is not this band but the smooth tests (tests/test_gpu_parity_targets.py).
+GEN_GRAD_CAP = 1e-2
+GEN_GRAD_FACTOR = 5.0
 GEN_GRAD_UNIFORM = 3.0
+GEN_GRAD_MIN_SHARE = 1e-4
 
 
-def check_gen_grad(gs, r32, r64, what):
-    """Asserts criteria (1) and (2) for one generator; returns (err ours, err fp32 oracle)."""
+def check_gen_grad(gs, r32, r64, what, fails=None):
+    """Criteria (1) and (2) for one generator; returns (err ours, err fp32 oracle).  Violations are appended to `fails`
+    (or asserted on the spot when there is no list)."""
     keys = list(r64)
     e_ours, e_ref = l2rel(gs, r64, keys), l2rel(r32, r64, keys)
-    assert e_ours <= max(GEN_GRAD_FACTOR * e_ref, ACT_TOL), ("generator gradient level", what, e_ours, e_ref)
+
+    def bad(msg):
+        if fails is None:
+            raise AssertionError(msg)
+        fails.append(msg)
+    if not e_ours <= max(GEN_GRAD_FACTOR * e_ref, GEN_GRAD_CAP):
+        bad(("generator gradient level", what, e_ours, e_ref))
     tot = np.sqrt(sum(float((r64[k].astype(np.float64) ** 2).sum()) for k in keys))
     if e_ours > ACT_TOL:                  # below that the level criterion alone already is the 1e-3 tolerance
         for k in keys:
             n = np.sqrt(float((r64[k].astype(np.float64) ** 2).sum()))
-            if n < 0.02 * tot:
+            if n < GEN_GRAD_MIN_SHARE * tot:
                 continue
             e_k = np.sqrt(float(((gs[k].astype(np.float64) - r64[k].astype(np.float64)) ** 2).sum())) / n
-            assert e_k <= e_ours * GEN_GRAD_UNIFORM, ("generator gradient: tensor above the common error level", what, k, e_k, e_ours)
+            if not e_k <= e_ours * GEN_GRAD_UNIFORM:
+                bad(("generator gradient: tensor above the common error level", what, k, e_k, e_ours))
     return e_ours, e_ref
 NETS = (("dis", "dis", "dis_%s_s"), ("disc", "dis_council", "dis_council_%s_s"), ("gen", "gen", "gen_%s_s"))
 
@@ -179,21 +199,24 @@ def iteration_vs_oracle(cga, cfg, size, batch, seed=1, report=None):
             close("mask_total_" + d, getattr(tr, 'loss_gen_mask_total_%s_s' % ab), o32.loss_mask_total[d])
         if cfg['mask_tv_w'] != 0 and cfg['iteration'] > cfg['focus_loss']['focus_loss_start_at_iter']:
             close("mask_tv_" + d, getattr(tr, 'loss_gen_mask_TV_%s_s' % ab), o32.loss_mask_tv[d])
-    # ---- gradients and post-step weights --------------------------------------------------------------------------------
+    # ---- gradients and post-step weights (every violation is collected: one GPU run reports them all) -----------------
+    fails = []
     for key, gs in got_g.items():
         kind = key[0]
         r64, r32 = g64[key], g32[key]
         assert set(gs) == set(r64), (key, set(gs) ^ set(r64))
         if kind == "gen":
-            e_ours, e_ref = check_gen_grad(gs, r32, r64, key)
+            e_ours, e_ref = check_gen_grad(gs, r32, r64, key, fails)
         else:
             e_ours, e_ref = l2rel(gs, r64), l2rel(r32, r64)
-            assert e_ours <= ACT_TOL, ("discriminator gradient", key, e_ours, e_ref)
+            if not e_ours <= ACT_TOL:
+                fails.append(("discriminator gradient", key, e_ours, e_ref))
         errs[("grad",) + key] = (e_ours, e_ref)
         keys = list(r64)
         w_ours, w_ref = mean_abs_diff(got_w[key], w64[key], keys), mean_abs_diff(w32[key], w64[key], keys)
         errs[("post",) + key] = (w_ours, w_ref)
-        assert w_ours <= max(2 * w_ref, 2e-6), ("post-step weights", key, w_ours, w_ref)
+        if not w_ours <= max(2 * w_ref, 2e-6):
+            fails.append(("post-step weights", key, w_ours, w_ref))
     if report is not None:
         print("\n[%s] losses (rel vs fp32 oracle): %s" % (report, {k[5:]: "%.1e" % v for k, v in errs.items()
                                                                  if isinstance(k, str)}))
@@ -204,4 +227,88 @@ def iteration_vs_oracle(cga, cfg, size, batch, seed=1, report=None):
               (report, {"%s/%s/%d" % k[1:]: ("%.1e" % v[0], "%.1e" % v[1]) for k, v in errs.items()
                         if not isinstance(k, str) and k[0] == "post"}))
     del tr
+    assert not fails, fails
     return errs
+
+
+def smooth_backward_errors(cga, cfg, size=64, batch=2, seed=21, head_scale=0.02, group_max=None, activ=None):
+    """The generator's backward chain alone (tests/test_gpu_parity_targets.py::test_generator_backward_chain_smooth_loss):
+    a linear objective sum(G_img * image) + sum(G_mask * mask) with fixed random G on the members of a council-2 trainer,
+    member-batched on the trainer's datapath, against the fp64 oracle.  Returns ({(member, tensor): l2-rel error},
+    {member: (image error, mask error)} max-abs / max), zero-gradient biases checked and left out."""
+    from council_gan_amd import ops
+    cfg = copy.deepcopy(cfg)
+    cfg['batch_size'] = batch
+    if activ is not None:
+        cfg['gen']['activ'] = activ          # networks.py:494-507: 'tanh' makes the whole generator smooth
+    B, S = batch, size
+    O.seed_all(seed)
+    tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
+    C = tr.council_size
+    d = tr._dirs[0]
+    gens = tr._nets('gen', d)
+    with torch.no_grad():
+        for gen in gens:
+            gen.dec.model[len(gen.dec.model) - 1].conv.weight.mul_(head_scale)
+    state = host_state(tr)
+    tr.cuda('cuda:0')
+    if group_max is not None:
+        tr._group_max = group_max
+    tr._hp_last = cfg
+    tr._ready()
+    x_a, _ = O.synthetic_batch(B, S)
+    g = torch.Generator().manual_seed(5)
+    style = torch.randn(B, cfg['gen']['style_dim'], 1, 1, generator=g)
+    k = gens[0].dec.num_of_mask_dim_to_add
+    up_im = torch.randn(C, B, 3, S, S, generator=g)
+    up_mask = torch.randn(C, B, k, S, S, generator=g)
+    x = tr._img(x_a, 'a')
+    groups = tr._plan_groups(x)
+    tr._pools['gen'].zero_grad()
+    cl = torch.channels_last
+    fwd = {}
+    with tr._fresh_mirrors('gen'):
+        for grp in groups:
+            n, m0 = len(grp), grp[0]
+            with ops.members(n):
+                xr = tr._rep(x, n)
+                gen = gens[m0]
+                fake = gen.decode(tr._content(d, grp, xr, need_grad=True), style.repeat(n, 1, 1, 1).cuda(), xr)
+                mask = gen.dec.mask_s
+                for j, m in enumerate(grp):
+                    fwd[m] = (np_(fake[j * B:(j + 1) * B]), np_(mask[j * B:(j + 1) * B]))
+                torch.autograd.backward([fake, mask],
+                                        [up_im[m0:m0 + n].reshape(n * B, 3, S, S).cuda().contiguous(memory_format=cl),
+                                         up_mask[m0:m0 + n].reshape(n * B, k, S, S).cuda().contiguous(memory_format=cl)])
+    torch.cuda.synchronize()
+    # a member-batched launch flags the lead member's gradient views only (optim.ParamPool.step): read every member's slice
+    got = {}
+    for grp in groups:
+        touched = {kk for kk, p in gens[grp[0]].named_parameters() if p._cg_grad._cg_touched}
+        for m in grp:
+            got[m] = {kk: np_(p._cg_grad) for kk, p in gens[m].named_parameters() if kk in touched}
+    errs, ferr = {}, {}
+    for m in range(C):
+        sd = {kk: torch.as_tensor(np.asarray(v)).double().clone().requires_grad_(not kk.endswith(('running_mean', 'running_var')))
+              for kk, v in state[d]['gen'][m].items()}
+        og = O.OracleGen(sd, cfg['gen'])
+        xd = x_a.double()
+        im = og.decode(og.encode_content(xd), style.double(), xd)
+        mk = og.mask_s
+        ferr[m] = (float(np.abs(fwd[m][0] - im.detach().numpy()).max() / np.abs(im.detach().numpy()).max()),
+                   float(np.abs(fwd[m][1] - mk.detach().numpy()).max() / np.abs(mk.detach().numpy()).max()))
+        torch.autograd.backward([im, mk], [up_im[m].double(), up_mask[m].double()])
+        ref = {kk: v.grad.numpy() for kk, v in sd.items() if v.requires_grad and v.grad is not None}
+        assert set(got[m]) == set(ref), set(got[m]) ^ set(ref)
+        for kk, r in ref.items():
+            n = float(np.sqrt((r ** 2).sum()))
+            e = float(np.sqrt(((got[m][kk].astype(np.float64) - r) ** 2).sum()))
+            if kk.endswith('conv.bias') and n < 1e-6 * float(np.sqrt((ref[kk[:-4] + 'weight'] ** 2).sum())):
+                # a bias in front of an instance norm: its gradient is identically zero, what is left is round-off --
+                # ours must be as negligible against the layer's weight gradient as the oracle's
+                wn = float(np.sqrt((ref[kk[:-4] + 'weight'] ** 2).sum()))
+                assert e <= 1e-5 * wn, ("zero-gradient bias", m, kk, e, wn)
+                continue
+            errs[(m, kk)] = e / n
+    del tr
+    return errs, ferr

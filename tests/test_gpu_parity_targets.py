@@ -41,7 +41,7 @@ def _cfg(name, council, iteration=60000):
 
 
 def test_council8_iteration_vs_oracle(cga):
-    """anime2face (b2a, three mask channels), council 8, full widths, 64x64, batch 1."""
+    """anime2face (b2a, three mask channels), council 8, full widths, 128x128, batch 1."""
     cfg = _cfg("anime2face_council_folder.yaml", 8)
     assert cfg['council']['numberOfCouncil_dis_relative_iteration'] == 4       # 4 of 7 colleagues, no refill
     random.seed(5)
@@ -57,91 +57,47 @@ def test_council8_iteration_vs_oracle(cga):
         return groups
     cga.Council_Trainer._plan_groups = spy
     try:
-        P.iteration_vs_oracle(cga, cfg, 64, 1, seed=6, report="anime2face 64^2 council 8 B1")
+        P.iteration_vs_oracle(cga, cfg, 128, 1, seed=6, report="anime2face 128^2 council 8 B1")
     finally:
         cga.Council_Trainer._plan_groups = orig
     if int(os.environ.get('CG_GROUP', '4')) == 4:
         assert seen['groups'] == [[0, 1, 2, 3], [4, 5, 6, 7]], seen      # two launches of four members
 
 
-def test_generator_backward_chain_smooth_loss(cga):
+@pytest.mark.parametrize("activ", ["tanh", "relu"])
+def test_generator_backward_chain_smooth_loss(cga, activ):
     """Every generator tensor's gradient against the fp64 oracle under a linear objective  sum(G_img * image) +
-    sum(G_mask * mask)  with fixed random G: no LSGAN / focus head, so no chaotic amplification -- what is compared is the
-    backward chain itself (mask/blend head, 1x1 head, upsampling convolutions, AdaIN + MLP, residual blocks, strided
-    convolutions, the 7x7 first layer), member-batched (two members in one launch) on the split-precision datapath.
-    The tanh head is kept out of saturation (the last layer's weights are scaled by 0.02).  With the saturated head of a
-    freshly initialised generator the upstream gradient field is carried by the few unsaturated pixels, and the ReLU sign
-    decisions that differ between ANY two fp32 evaluations (|y| ~ 1e-6 elements of the 1x1 head at full resolution) then
-    move every upstream tensor by the same ~2e-3 -- measured on the reference's own arithmetic (CPU oracle fp32 vs fp64:
-    2.2e-3 on all 60 tensors; an exact tanh derivative does not change it) -- which would drown the comparison; out of
-    saturation that floor is 1.5e-4."""
-    from council_gan_amd import ops
+    sum(G_mask * mask)  with fixed random G: no LSGAN / focus head.  What is compared is the backward chain itself (mask /
+    blend head, 1x1 head, upsampling convolutions, AdaIN + MLP, residual blocks, strided convolutions, the 7x7 first layer,
+    every bias), member-batched (two members in one launch) on the benchmarked split-precision datapath, full widths.
+
+    [tanh]  gen.activ = 'tanh' (networks.py:494-507): with a smooth activation the whole generator is smooth, nothing is
+            decided by the sign of a round-off-sized number, and EVERY tensor must agree with fp64 to 1e-3 (the CPU oracle
+            in fp32: 8e-6; measured here: ~1e-5).  This is the test that pins the backward kernels tensor by tensor.
+    [relu]  the shipped activation: ReLU sign decisions on pre-activations that vanish to within the forward round-off
+            flip whole upstream contributions on and off ("flip noise", tests/parity_util.py) -- the CPU oracle's own fp32-vs-
+            fp64 gap here is 1.5e-4 on every tensor upstream of the 1x1 head, the exact-fp32 MFMA datapath's 1-2e-3, the
+            split-precision datapath's 1-4e-3.  Asserted: the generator-gradient band (level cap 1e-2) and that no tensor
+            sits above 3 x the common level; the tensors downstream of the last ReLU (dec.model.9) must meet 1e-3.
+    The tanh head is kept out of saturation (the last layer's weights are scaled by 0.02): with the saturated head of a
+    freshly initialised generator the upstream gradient is carried by the few unsaturated pixels and a single flip moves
+    every upstream tensor by ~2e-3 in the reference's own arithmetic (CPU oracle fp32 vs fp64: 2.2e-3 on all 60 tensors)."""
     cfg = _cfg("male2female_council_folder.yaml", 2)
-    cfg['batch_size'] = 2
-    B, S, C = 2, 64, 2
-    O.seed_all(21)
-    tr = cga.Council_Trainer(copy.deepcopy(cfg), 'cuda:0')
-    assert tr._split_fwd
-    with torch.no_grad():
-        for gen in tr.gen_a2b_s:
-            gen.dec.model[9].conv.weight.mul_(0.02)
-    state = P.host_state(tr)
-    tr.cuda('cuda:0')
-    tr._hp_last = cfg
-    tr._ready()
-    x_a, _ = O.synthetic_batch(B, S)
-    g = torch.Generator().manual_seed(5)
-    style = torch.randn(B, cfg['gen']['style_dim'], 1, 1, generator=g)
-    up_im = torch.randn(C, B, 3, S, S, generator=g)
-    up_mask = torch.randn(C, B, 3, S, S, generator=g)
-
-    x = tr._img(x_a, 'a')
-    groups = tr._plan_groups(x)
-    assert [list(grp) for grp in groups] == [[0, 1]]
-    pool = tr._pools['gen']
-    pool.zero_grad()
-    with tr._fresh_mirrors('gen'), ops.members(C):
-        xr = tr._rep(x, C)
-        gen = tr.gen_a2b_s[0]
-        s_dev = style.repeat(C, 1, 1, 1).cuda()
-        fake = gen.decode(tr._content('a2b', groups[0], xr, need_grad=True), s_dev, xr)
-        mask = gen.dec.mask_s
-        assert fake.shape == (C * B, 3, S, S) and mask.shape == (C * B, 3, S, S)
-        cl = torch.channels_last
-        torch.autograd.backward([fake, mask], [up_im.view(C * B, 3, S, S).cuda().contiguous(memory_format=cl),
-                                               up_mask.view(C * B, 3, S, S).cuda().contiguous(memory_format=cl)])
-    torch.cuda.synchronize()
-    # a member-batched launch flags the lead member's gradient views only (optim.ParamPool.step): read every member's slice
-    got = []
-    for m, net in enumerate(tr.gen_a2b_s):
-        touched = {k for k, p in tr.gen_a2b_s[0].named_parameters() if p._cg_grad._cg_touched}
-        got.append({k: P.np_(p._cg_grad) for k, p in net.named_parameters() if k in touched})
-
-    worst = {}
-    for m in range(C):
-        sd = {k: torch.as_tensor(np.asarray(v)).double().clone().requires_grad_(not k.endswith(('running_mean', 'running_var')))
-              for k, v in state['a2b']['gen'][m].items()}
-        og = O.OracleGen(sd, cfg['gen'])
-        xd = x_a.double()
-        im = og.decode(og.encode_content(xd), style.double(), xd)
-        torch.autograd.backward([im, og.mask_s], [up_im[m].double(), up_mask[m].double()])
-        ref = {k: v.grad.numpy() for k, v in sd.items() if v.requires_grad and v.grad is not None}
-        assert set(got[m]) == set(ref), set(got[m]) ^ set(ref)
-        for k, r in ref.items():
-            n = float(np.sqrt((r ** 2).sum()))
-            e = float(np.sqrt(((got[m][k].astype(np.float64) - r) ** 2).sum()))
-            if k.endswith('conv.bias') and n < 1e-6 * float(np.sqrt((ref[k[:-4] + 'weight'] ** 2).sum())):
-                # a bias in front of an instance norm: its gradient is identically zero, what is left is round-off --
-                # ours must be as negligible against the layer's weight gradient as the oracle's
-                wn = float(np.sqrt((ref[k[:-4] + 'weight'] ** 2).sum()))
-                assert e <= 1e-5 * wn, ("zero-gradient bias", m, k, e, wn)
-                continue
-            worst[(m, k)] = e / n
-    bad = {k: v for k, v in worst.items() if not v <= P.ACT_TOL}
+    worst, fwd = P.smooth_backward_errors(cga, cfg, size=64, batch=2, activ=activ)
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
-    print("\n[smooth-loss generator backward] %d tensors, worst l2-rel vs fp64: %s"
-          % (len(worst), [("%d/%s" % k, "%.1e" % v) for k, v in top]))
-    assert not bad, bad
+    print("\n[smooth-loss generator backward, %s] %d tensors, worst l2-rel vs fp64: %s; forward (image, mask) max-abs/max: %s"
+          % (activ, len(worst), [("%d/%s" % k, "%.1e" % v) for k, v in top], fwd))
+    assert max(max(v) for v in fwd.values()) <= P.ACT_TOL, fwd
+    if activ == "tanh":
+        bad = {k: v for k, v in worst.items() if not v <= P.ACT_TOL}
+        assert not bad, bad
+        return
+    for m in sorted({m for m, _ in worst}):
+        mine = {k: v for (mm, k), v in worst.items() if mm == m}
+        level = float(np.median(list(mine.values())))
+        assert level <= P.GEN_GRAD_CAP, (m, level)
+        assert max(mine.values()) <= max(P.GEN_GRAD_UNIFORM * level, P.ACT_TOL), (m, level, max(mine, key=mine.get), max(mine.values()))
+        assert mine['dec.model.9.conv.weight'] <= P.ACT_TOL and mine['dec.model.9.conv.bias'] <= P.ACT_TOL, mine
 
 
 def test_member_grouping_is_exact_on_fp32_datapath(cga):

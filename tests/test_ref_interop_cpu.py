@@ -15,3 +15,10 @@ def test_reference_resume_reads_our_checkpoints_and_we_read_theirs():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "ref_interop.py")], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "INTEROP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree not present")
+def test_oracle_generator_matches_reference_for_every_activation():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "ref_activations.py")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "ACTIVATIONS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
