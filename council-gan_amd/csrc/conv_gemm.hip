@@ -1550,11 +1550,14 @@ struct FwdAmax {
 };
 static thread_local FwdAmax fwd_amax;
 constexpr int CG_AMAX_SLOTS_MAX = 1024;     // == CG_AMAX_MAX_SLOTS of conv_x3.inc (state[2 .. 2 + 1024))
+__global__ __launch_bounds__(256) void zero_slots_kernel(float* __restrict__ slots) { slots[blockIdx.x * 256 + threadIdx.x] = 0.f; }
 // slots a launch of `blocks` blocks fills (block_amax_store): one each, or 1024 shared ones that must start at zero
 static int amax_slots_for(long blocks, float* state, hipStream_t st) {
     if (blocks <= CG_AMAX_SLOTS_MAX) return (int)blocks;
     if (tune().no_amax_atomic) return 0;      // A/B switch
-    (void)hipMemsetAsync(state + 2, 0, CG_AMAX_SLOTS_MAX * sizeof(float), st);
+    // a KERNEL, not hipMemsetAsync: a memset node captured into a hipGraph did not keep its place in front of the kernel that
+    // fills the slots when the graph was replayed (measured: the consumer then saw zeroed maxima), a kernel node does
+    hipLaunchKernelGGL(zero_slots_kernel, dim3(CG_AMAX_SLOTS_MAX / 256), dim3(256), 0, st, state + 2);
     return CG_AMAX_SLOTS_MAX;
 }
 

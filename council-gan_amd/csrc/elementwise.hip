@@ -348,9 +348,15 @@ __global__ void l1_mean_bwd_kernel(const float* __restrict__ a, const float* __r
 }
 
 // ---- torch.optim.Adam (L2 weight decay), trainer_council.py:170-179 ----------------------------
+// hyper_dev (optional): {step_size, sqrt(bias_correction2)} read from device memory instead of the kernel arguments -- the two
+// numbers that change from step to step, so that a launch captured in a hipGraph stays valid (cg_adam_step_dev)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, size_t n, float beta1, float beta2, float eps, float wd,
-                            float step_size, float bc2_sqrt, long long mstride) {
+                            float step_size, float bc2_sqrt, long long mstride, const float* __restrict__ hyper_dev) {
+    if (hyper_dev) {
+        step_size = hyper_dev[0];
+        bc2_sqrt = hyper_dev[1];
+    }
     const float w1 = 1.f - beta1;
     const long long mo = (long long)blockIdx.y * mstride;       // blockIdx.y = council member (same run of its pool slice)
     p += mo; g += mo; m += mo; v += mo;
@@ -407,8 +413,10 @@ __global__ void gen_total_kernel(const float* __restrict__ focus, const float* _
 // ring[pos % n] = value ; optional w = mean(ring_a) / mean(ring_b)  (trainer_council.py:518-524,576-581)
 // blockIdx.x = council member: rings [member][n], value / w_out one entry per member
 __global__ void ring_kernel(float* __restrict__ ring_a, float* __restrict__ ring_b, int n, int pos,
-                            const float* __restrict__ value, float* __restrict__ w_out, int push_b) {
+                            const float* __restrict__ value, float* __restrict__ w_out, int push_b,
+                            const int32_t* __restrict__ pos_dev) {
     if (threadIdx.x != 0) return;
+    if (pos_dev) pos = pos_dev[0];      // write position from device memory (hipGraph-captured launches)
     ring_a += (size_t)blockIdx.x * n;
     if (ring_b) ring_b += (size_t)blockIdx.x * n;
     value += blockIdx.x;
@@ -640,7 +648,28 @@ extern "C" int cg_adam_step_g(float* p, const float* g, float* m, float* v, size
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n), nmember), dim3(256), 0, cg_s(stream), p, g, m, v, n, beta1, beta2, eps,
-                       weight_decay, step_size, bc2_sqrt, mstride);
+                       weight_decay, step_size, bc2_sqrt, mstride, (const float*)nullptr);
+    CG_LAUNCH_CHECK("adam_kernel");
+    return CG_OK;
+}
+// The two per-step scalars of cg_adam_step_g as the HOST computes them (double precision, rounded once): out[0] = lr /
+// (1 - beta1^step), out[1] = sqrt(1 - beta2^step).  cg_adam_step_dev with these two floats in device memory is bit-identical
+// to cg_adam_step_g(..., lr, ..., step).
+extern "C" int cg_adam_hyper(float lr, float beta1, float beta2, int step, float* out2_host) {
+    CG_CHECK_ARG(out2_host && step >= 1, "cg_adam_hyper: bad args");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    out2_host[0] = (float)((double)lr / bc1);
+    out2_host[1] = (float)sqrt(bc2);
+    return CG_OK;
+}
+extern "C" int cg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, int nmember, long long mstride,
+                                float beta1, float beta2, float eps, float weight_decay, const float* hyper_dev,
+                                cg_stream_t stream) {
+    CG_CHECK_ARG(p && g && m && v && hyper_dev && nmember >= 1 && (nmember == 1 || mstride > 0), "cg_adam_step_dev: bad args");
+    if (n == 0) return CG_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n), nmember), dim3(256), 0, cg_s(stream), p, g, m, v, n, beta1, beta2, eps,
+                       weight_decay, 0.f, 1.f, mstride, hyper_dev);
     CG_LAUNCH_CHECK("adam_kernel");
     return CG_OK;
 }
@@ -673,7 +702,23 @@ extern "C" int cg_gen_total(const float* focus, const float* adv, const float* l
 extern "C" int cg_ring_push_g(float* ring, int n, int pos, const float* value, int nmember, cg_stream_t stream) {
     CG_CHECK_ARG(ring && value && n > 0 && pos >= 0 && nmember > 0, "cg_ring_push: bad args");
     hipLaunchKernelGGL(ring_kernel, dim3(nmember), dim3(64), 0, cg_s(stream), ring, (float*)nullptr, n, pos, value,
-                       (float*)nullptr, 0);
+                       (float*)nullptr, 0, (const int32_t*)nullptr);
+    CG_LAUNCH_CHECK("ring_kernel");
+    return CG_OK;
+}
+// the same two operations with the write position read from device memory (pos_dev[0] >= 0)
+extern "C" int cg_ring_push_dev(float* ring, int n, const int32_t* pos_dev, const float* value, int nmember, cg_stream_t stream) {
+    CG_CHECK_ARG(ring && value && pos_dev && n > 0 && nmember > 0, "cg_ring_push_dev: bad args");
+    hipLaunchKernelGGL(ring_kernel, dim3(nmember), dim3(64), 0, cg_s(stream), ring, (float*)nullptr, n, 0, value,
+                       (float*)nullptr, 0, pos_dev);
+    CG_LAUNCH_CHECK("ring_kernel");
+    return CG_OK;
+}
+extern "C" int cg_loss_match_dev(float* ring_gan, float* ring_council, int n, const int32_t* pos_dev, const float* council_loss,
+                                 float* w_out, int nmember, cg_stream_t stream) {
+    CG_CHECK_ARG(ring_gan && ring_council && council_loss && w_out && pos_dev && n > 0 && nmember > 0, "cg_loss_match_dev: bad args");
+    hipLaunchKernelGGL(ring_kernel, dim3(nmember), dim3(64), 0, cg_s(stream), ring_gan, ring_council, n, 0, council_loss,
+                       w_out, 1, pos_dev);
     CG_LAUNCH_CHECK("ring_kernel");
     return CG_OK;
 }
@@ -681,7 +726,7 @@ extern "C" int cg_loss_match_g(float* ring_gan, float* ring_council, int n, int 
                                float* w_out, int nmember, cg_stream_t stream) {
     CG_CHECK_ARG(ring_gan && ring_council && council_loss && w_out && n > 0 && pos >= 0 && nmember > 0, "cg_loss_match: bad args");
     hipLaunchKernelGGL(ring_kernel, dim3(nmember), dim3(64), 0, cg_s(stream), ring_gan, ring_council, n, pos, council_loss,
-                       w_out, 1);
+                       w_out, 1, (const int32_t*)nullptr);
     CG_LAUNCH_CHECK("ring_kernel");
     return CG_OK;
 }

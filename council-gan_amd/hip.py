@@ -77,6 +77,10 @@ _SIGS = {
                                c_int, c_int, _P, _P]),
     "cg_adam_step_g": (c_int, [_P, _P, _P, _P, c_size_t, c_int, ctypes.c_longlong, c_float, c_float, c_float, c_float, c_float,
                                c_int, _P]),
+    "cg_adam_hyper": (c_int, [c_float, c_float, c_float, c_int, POINTER(c_float)]),
+    "cg_adam_step_dev": (c_int, [_P, _P, _P, _P, c_size_t, c_int, ctypes.c_longlong, c_float, c_float, c_float, c_float, _P, _P]),
+    "cg_ring_push_dev": (c_int, [_P, c_int, _P, _P, c_int, _P]),
+    "cg_loss_match_dev": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, _P]),
     "cg_ring_push_g": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
     "cg_loss_match_g": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, _P]),
     "cg_gather_rows2": (c_int, [_P, _P, _P, _P, c_int, c_size_t, _P]),

@@ -419,8 +419,9 @@ class _LossVectors:
         key = (tuple(tgt), tuple(wt), str(device))
         v = self._cache.get(key)
         if v is None:
-            v = (torch.tensor(tgt, dtype=torch.float32, device=device),
-                 torch.tensor(wt, dtype=torch.float32, device=device))
+            h = (torch.tensor(tgt, dtype=torch.float32).pin_memory(), torch.tensor(wt, dtype=torch.float32).pin_memory())
+            v = (h[0].to(device, non_blocking=True), h[1].to(device, non_blocking=True))     # no host stall on a miss
+            v[0]._cg_host = h
             if len(self._cache) > 256:
                 self._cache.clear()
             self._cache[key] = v
@@ -560,9 +561,17 @@ class MsImageDisCouncil(nn.Module):
         with how often; input: the one conditioning batch [B].  Discriminator batch of member m:
         [own | cmp_j1 | cmp_j2 | ...] with per-sample loss weights; every member has the same number of blocks."""
         n = ops.group_n()
+        b = x_full.shape[0] // n
+        idx, idx_in, tgt, wt = self.plan_members(picks, n, b, fake_weight, weight)
+        tgt, wt = self._vec.get(tgt, wt, x_full.device)
+        return self.calc_dis_loss_planned(x_full, x_cmp, input, idx, idx_in, tgt, wt, None)
+
+    @staticmethod
+    def plan_members(picks, n, b, fake_weight, weight=1.0):
+        """Host half of calc_dis_loss_members: (rows of the discriminator batch as take_rows indices into [x_full | x_cmp],
+        rows of the conditioning batch, LSGAN targets, per-sample loss weights) as plain lists."""
         if len(picks) != n:
             raise ValueError("one pick list per member of the launch")
-        b = x_full.shape[0] // n
         u = len(picks[0])
         if any(len(p) != u for p in picks):
             raise ValueError("members of one launch must compare against the same number of distinct colleagues")
@@ -576,11 +585,16 @@ class MsImageDisCouncil(nn.Module):
                 tgt += [1.0] * b
                 wt += [weight * mult] * b
             idx_in += list(range(b)) * (1 + u)
-        x = ops.take_rows(x_full, x_cmp, idx)
+        return idx, idx_in, tgt, wt
+
+    def calc_dis_loss_planned(self, x_full, x_cmp, input, idx, idx_in, tgt_dev, wt_dev, idx_dev):
+        """Device half: `idx` / `idx_in` from plan_members (`idx_dev`: the same rows as a device vector the caller keeps
+        current -- the colleague picks change every iteration, graphs.HostInputs), targets / weights as device vectors."""
+        b = x_full.shape[0] // ops.group_n()
+        x = ops.take_rows(x_full, x_cmp, idx, idx_dev=idx_dev)
         x_in = ops.take_rows(input, None, idx_in)
         outs = self.forward(x, x_in)
-        tgt, wt = self._vec.get(tgt, wt, x_full.device)
-        return ops.lsgan_loss(outs, tgt, wt, b)
+        return ops.lsgan_loss(outs, tgt_dev, wt_dev, b)
 
     def calc_gen_loss(self, input_fake, input, input_real=None, weight=1.0):
         """networks.py:188-215 (one loss per member under ops.members(n); `input` is then the member-major repetition

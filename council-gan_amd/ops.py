@@ -1034,14 +1034,19 @@ def _index_tensor(idx, device):
     if t is None:
         if len(_idx_cache) > 512:
             _idx_cache.clear()
-        t = _idx_cache[key] = torch.tensor(list(idx), dtype=torch.int32, device=device)
+        # through pinned memory: a pageable-memory upload blocks the host until the stream has drained (8 ms per miss
+        # inside a training step)
+        h = torch.tensor(list(idx), dtype=torch.int32).pin_memory()
+        t = _idx_cache[key] = h.to(device, non_blocking=True)
+        t._cg_host = h                 # keeps the pinned source alive until the copy has certainly run
     return t
 
 
-def take_rows(a, b, idx, out=None):
+def take_rows(a, b, idx, out=None, idx_dev=None):
     """out[i] = a[idx[i]] if idx[i] >= 0 else b[-idx[i] - 1] along the batch dimension (NHWC rows): how the discriminator
     batches [own fake | real] / [own translation | colleagues' translations] of all members are assembled -- one copy
-    kernel instead of torch.cat.  `idx` is a host sequence (cached on the device by value)."""
+    kernel instead of torch.cat.  `idx` is a host sequence (cached on the device by value) -- or, with `idx_dev` (an int32
+    device vector the caller keeps current, graphs.HostInputs), just its length."""
     a = nhwc(a) if a.dim() == 4 else a.contiguous()
     if b is not None:
         b = nhwc(b) if b.dim() == 4 else b.contiguous()
@@ -1057,8 +1062,10 @@ def take_rows(a, b, idx, out=None):
     elif out.shape[0] != len(idx) or out[0].numel() != row or not (out.is_contiguous(memory_format=CL) if out.dim() == 4
                                                                     else out.is_contiguous()):
         raise ValueError("take_rows: `out` must be a dense NHWC block of len(idx) rows")
-    check(_lib().cg_gather_rows2(ptr(a), ptr(b), ptr(_index_tensor(idx, a.device)), ptr(out), len(idx), row, stream()),
-          "cg_gather_rows2")
+    if idx_dev is not None and (idx_dev.dtype != torch.int32 or idx_dev.numel() != len(idx)):
+        raise ValueError("take_rows: idx_dev must be an int32 vector of len(idx) entries")
+    check(_lib().cg_gather_rows2(ptr(a), ptr(b), ptr(idx_dev if idx_dev is not None else _index_tensor(idx, a.device)),
+                                 ptr(out), len(idx), row, stream()), "cg_gather_rows2")
     return out
 
 

@@ -231,44 +231,91 @@ class ParamPool:
                 p._cg_grad._cg_touched = False
                 p.grad = p._cg_grad
 
-    @torch.no_grad()
-    def step(self, k0=0, n=None, lockstep=False):
-        """Adam step of members [k0, k0+n).  `lockstep`: the members were updated by member-batched launches that only
-        flagged the FIRST member's gradient views as written -- its pattern holds for all of them; one launch per run of
-        touched parameters serves every member (their slices are `stride` apart)."""
-        n = len(self.opts) - k0 if n is None else n
-        opts = self.opts[k0:k0 + n]
+    def _same(self, opts, lockstep):
+        """Can members `opts` take ONE launch per run of touched parameters?  (identical step counts and hyper-parameters; a
+        member-batched launch writes every member's slice but flags only the lead's gradient views -- a member whose own
+        flags show MORE than the lead's was touched outside a batched launch and steps on its own)"""
         lead = opts[0]
+        if len(opts) == 1:
+            return True
         hyper = lambda o: tuple((k, tuple(v) if isinstance(v, (list, tuple)) else v)      # noqa: E731
                                 for k, v in sorted(o.param_groups[0].items()) if k not in ("params", "initial_lr"))
         same = lockstep and all(o._steps == lead._steps and hyper(o) == hyper(lead) for o in opts[1:])
         if lockstep:
-            # a member-batched launch writes every member's slice but flags only the lead's views.  A member whose own
-            # flags show MORE than the lead's (touched outside a batched launch) keeps them and steps on its own.
             for o in opts[1:]:
                 for p, q in zip(o._params, lead._params):
                     if p._cg_grad._cg_touched and not q._cg_grad._cg_touched:
                         same = False
                     p._cg_grad._cg_touched = p._cg_grad._cg_touched or q._cg_grad._cg_touched
-        if not same or n == 1:
+        return same
+
+    def plan_hyper(self, k0, n):
+        """The per-run {step_size, sqrt(bias_correction2)} pairs the NEXT step of members [k0, k0+n) will use, as a host
+        tensor [runs, 2] (cg_adam_hyper: the very floats cg_adam_step_g computes) -- or None while the runs of that step
+        are not known yet (before its first execution).  Staged into device memory by the trainer (graphs.HostInputs) so
+        that the step's launches can be captured in a hipGraph."""
+        runs = self.__dict__.setdefault('_runs', {}).get((k0, n))
+        if runs is None:
+            return None
+        import ctypes
+        lead = self.opts[k0]
+        grp = lead.param_groups[0]
+        b1, b2 = grp["betas"]
+        out = torch.empty(len(runs), 2, dtype=torch.float32)
+        buf = (ctypes.c_float * 2)()
+        lib = hip.load()
+        for r, (i0, _i1) in enumerate(runs):
+            check(lib.cg_adam_hyper(float(grp["lr"]), float(b1), float(b2), lead._steps[i0] + 1, buf), "cg_adam_hyper")
+            out[r, 0], out[r, 1] = buf[0], buf[1]
+        return out
+
+    def advance(self, k0, n, runs):
+        """Host bookkeeping of one executed step of members [k0, k0+n): step counts of the touched runs, weight versions."""
+        for o in self.opts[k0:k0 + n]:
+            for i0, i1 in runs:
+                for k in range(i0, i1):
+                    o._steps[k] += 1
+            o.version += 1
+
+    @torch.no_grad()
+    def step(self, k0=0, n=None, lockstep=False, hyper=None, advance=True):
+        """Adam step of members [k0, k0+n).  `lockstep`: the members were updated by member-batched launches that only
+        flagged the FIRST member's gradient views as written -- its pattern holds for all of them; one launch per run of
+        touched parameters serves every member (their slices are `stride` apart).  `hyper`: device tensor [runs, 2] from
+        plan_hyper() -- the per-step scalars then come from device memory (same floats, bit-identical update) and the
+        launches are valid under hipGraph replay.  `advance=False`: launch only; the caller applies advance() itself (once
+        per execution of a captured step).  Returns the runs it launched (None when the members stepped one by one)."""
+        n = len(self.opts) - k0 if n is None else n
+        opts = self.opts[k0:k0 + n]
+        lead = opts[0]
+        if not self._same(opts, lockstep):
+            if hyper is not None:
+                raise hip.HipError("members with different step counts / hyper-parameters cannot take a graph-captured step")
             for o in opts:
                 o.step()
-            return
+            self.__dict__.setdefault('_runs', {})[(k0, n)] = None
+            return None
         f = lead.flat
         grp = lead.param_groups[0]
         b1, b2 = grp["betas"]
         lib = hip.load()
-        for i0, i1 in lead.touched_runs():
+        runs = lead.touched_runs()
+        if hyper is not None and tuple(hyper.shape) != (len(runs), 2):
+            raise hip.HipError("staged Adam scalars do not match the step's parameter runs")
+        for r, (i0, i1) in enumerate(runs):
             off = f["offs"][i0]
             cnt = f["offs"][i1 - 1] + f["sizes"][i1 - 1] - off
-            step = lead._steps[i0] + 1
             base = k0 * self.stride + off
             sl = slice(base, base + cnt)
-            check(lib.cg_adam_step_g(ptr(self.data[sl]), ptr(self.grad[sl]), ptr(self.m[sl]), ptr(self.v[sl]), cnt, n,
-                                     self.stride, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
-                                     float(grp["weight_decay"]), step, stream()), "cg_adam_step_g")
-            for o in opts:
-                for k in range(i0, i1):
-                    o._steps[k] = step
-        for o in opts:
-            o.version += 1
+            if hyper is not None:
+                check(lib.cg_adam_step_dev(ptr(self.data[sl]), ptr(self.grad[sl]), ptr(self.m[sl]), ptr(self.v[sl]), cnt, n,
+                                           self.stride, float(b1), float(b2), float(grp["eps"]), float(grp["weight_decay"]),
+                                           ptr(hyper[r]), stream()), "cg_adam_step_dev")
+            else:
+                check(lib.cg_adam_step_g(ptr(self.data[sl]), ptr(self.grad[sl]), ptr(self.m[sl]), ptr(self.v[sl]), cnt, n,
+                                         self.stride, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
+                                         float(grp["weight_decay"]), lead._steps[i0] + 1, stream()), "cg_adam_step_g")
+        self.__dict__.setdefault('_runs', {})[(k0, n)] = runs
+        if advance:
+            self.advance(k0, n, runs)
+        return runs

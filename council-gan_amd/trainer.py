@@ -30,6 +30,7 @@ members every member is replicated, each replica takes a slice of the batch and 
 averaged with one all-reduce per optimizer step (parallel.py).
 """
 import contextlib
+import gc
 import os
 import random
 import warnings
@@ -42,6 +43,7 @@ from . import hip, ops
 from .hip import check, ptr, stream
 from .networks import AdaINGen, MsImageDis, MsImageDisCouncil
 from .optim import FlatAdam, ParamPool
+from .graphs import HostInputs, Segment
 from .parallel import CouncilShard
 from .utils import get_model_list, get_scheduler, weights_init
 
@@ -72,6 +74,7 @@ class Council_Trainer(nn.Module):
         self.numberOfCouncil_dis_relative_iteration_conf = hp['council']['numberOfCouncil_dis_relative_iteration']
         self.discriminetro_less_style_by_conf = hp['council']['discriminetro_less_style_by']
         self.cuda_device = cuda_device
+        self._hp_cfg = hp
         self.shard = shard if shard is not None else CouncilShard.from_env(self.council_size)
 
         # every variable ending in '_conf' is displayed in the tensorboard logs (trainer_council.py:37-68)
@@ -265,7 +268,19 @@ class Council_Trainer(nn.Module):
         # (members replicated over several ranks: both updates issue collectives -- the replicas' gradient all-reduce from
         # either stream, the image all-gather -- on different communicators; until that has run on RCCL the two updates
         # stay on one stream there unless CG_OVERLAP_UPDATES=1 asks for the overlap)
-        self._overlap = os.environ.get('CG_OVERLAP_UPDATES', '0' if self.shard.dp > 1 else '1') != '0'
+        # hipGraph mode (CG_GRAPH=1 / cfg['cg_graph']): the device work of every update is captured once per (shapes,
+        # schedule flags) and replayed; the host only refreshes the static input buffers (graphs.HostInputs).  Host cost
+        # per iteration drops from ~17 ms of Python to < 1 ms -- what a rank needs once it holds ONE member (20 ms of GPU
+        # work per iteration).  The two discriminator-side updates then stay on the caller's stream (a graph is replayed
+        # on one stream); replicated members (gradient all-reduces inside the update) keep the eager path.
+        self._graph_mode = str(self._hp_cfg.get('cg_graph', os.environ.get('CG_GRAPH', '0'))) == '1' and self.shard.dp == 1
+        self._graph_warmup = max(1, int(os.environ.get('CG_GRAPH_WARMUP', '1')))
+        self._hin = HostInputs(dev)
+        self._segs, self._recording, self._gx = {}, None, {}
+        self._iter_eager, self._phase = True, 0
+        self._overlap = os.environ.get('CG_OVERLAP_UPDATES', '0' if (self.shard.dp > 1 or self._graph_mode) else '1') != '0'
+        if self._graph_mode and self._overlap:
+            raise hip.HipError("CG_GRAPH=1 replays each update on one stream: it excludes CG_OVERLAP_UPDATES=1")
         self._side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if self._overlap else []
         self._e0 = None
         n = min(int(os.environ.get('CG_MEMBER_STREAMS', '2')), L)
@@ -335,6 +350,17 @@ class Council_Trainer(nn.Module):
         ent = self._img_cache.get(slot) if slot is not None else None
         if ent is not None and ent[0] is x and ent[1] == x._version:
             return ent[2]
+        if slot is not None and self._graph_mode:
+            # graph mode: the batch lives in ONE static NHWC buffer per input slot (captured kernels read its address)
+            st = self._gx.get(slot)
+            if st is None or st.shape != x.shape:
+                if st is not None:
+                    self._hin.generation += 1
+                st = self._gx[slot] = torch.empty(tuple(x.shape), dtype=torch.float32, device=self._device,
+                                                  memory_format=torch.channels_last)
+            st.copy_(x, non_blocking=True)
+            self._img_cache[slot] = (x, x._version, st)
+            return st
         y = x.to(self._device, dtype=torch.float32)
         if slot is not None:
             y = self.shard.batch_slice(y)                  # training batches: this rank's samples (parallel.py)
@@ -449,6 +475,116 @@ class Council_Trainer(nn.Module):
         if tok is not None:
             tok[0].wait_stream(tok[1])        # the caller's stream continues behind the side stream (no host wait)
 
+    # ------------------------------------------------------------------------------------
+    # hipGraph segments (graphs.py)
+    # ------------------------------------------------------------------------------------
+    def _effect(self, fn):
+        """A host-side effect of an update's device work (optimizer step counts, weight versions, ring positions): applied
+        now, and -- when the surrounding body is being captured -- remembered so that every replay repeats it."""
+        if self._recording is not None:
+            self._recording.append(fn)       # capture runs no kernel: the effect follows the replay (see _run)
+        else:
+            fn()
+
+    def _run(self, key, body):
+        """Run one segment of an update.  Eager mode: body().  Graph mode: `_graph_warmup` eager executions per key (they
+        create the cached constants and size the workspaces), then ONE capture, then replays.  `body` returns a dict of
+        trainer attributes (the loss lists train.py logs): tensors of a captured body live in the graph's private pool
+        and hold the replay's results."""
+        if not self._graph_mode:
+            out = body()
+        else:
+            # The segments of one iteration hand tensors to each other (the repeated batch, the content codes and their
+            # autograd tape, the translations): a segment may REPLAY -- or be CAPTURED -- only while every earlier segment
+            # of this iteration replayed or was captured in it, so that what it reads lives at static addresses of a graph
+            # pool.  Once one segment of an iteration runs eagerly (warm-up of a new key, a moved input buffer, an unusual
+            # call order), the rest of that iteration runs eagerly too (self._iter_eager, reset by dis_update).
+            seg = self._segs.get(key)
+            if seg is None:
+                seg = self._segs[key] = Segment()
+            if seg.graph is not None and seg.generation != self._hin.generation:
+                seg.graph, seg.warm = None, 0                      # a static input buffer moved: capture again
+            if self._iter_eager or (seg.graph is None and seg.warm < self._graph_warmup):
+                seg.warm += 1
+                self._iter_eager = True
+                out = body()
+            else:
+                if seg.graph is None:
+                    # a captured body must not bake the address of a tensor an EAGER pass allocated and a later refresh
+                    # frees (the prepared data-gradient weights cached per weight version): it prepares its own
+                    for pool in self._pools.values():
+                        if pool.split is not None:
+                            pool.split._dgrad = {}
+                    cur = torch.cuda.current_stream()
+                    cap = self.__dict__.get('_cap_stream')
+                    if cap is None:
+                        cap = self.__dict__['_cap_stream'] = torch.cuda.Stream(device=self._device)
+                    cap.wait_stream(cur)
+                    g = torch.cuda.CUDAGraph()
+                    self._recording = []
+                    # no garbage collection inside the capture: collecting a dead trainer's CUDAGraph there would call
+                    # hipGraphDestroy on a capturing thread ("operation not permitted when stream is capturing")
+                    gc.collect()
+                    gc_was_on = gc.isenabled()
+                    gc.disable()
+                    try:
+                        with torch.cuda.graph(g, stream=cap):
+                            seg.out = body()
+                        seg.effects = self._recording
+                    finally:
+                        self._recording = None
+                        if gc_was_on:
+                            gc.enable()
+                    cur.wait_stream(cap)
+                    seg.graph, seg.generation = g, self._hin.generation
+                seg.graph.replay()
+                for fn in seg.effects:
+                    fn()
+                out = seg.out
+        for k, v in out.items():
+            setattr(self, k, v)
+
+    def _static(self, name, t):
+        """Graph mode, several ranks: the result of an eager collective is copied into a static buffer (captured kernels
+        read one address); otherwise `t` itself."""
+        if not self._graph_mode or self.shard.world_size == 1:
+            return t
+        st = self._gx.get(name)
+        if st is None or st.shape != t.shape:
+            if st is not None:
+                self._hin.generation += 1
+            st = self._gx[name] = torch.empty(tuple(t.shape), dtype=t.dtype, device=t.device, memory_format=torch.channels_last)
+        st.copy_(t)
+        return st
+
+    def _stage_hyper(self, kind, groups):
+        """{first local member of a group: device [runs, 2] tensor of its next Adam step's scalars} (optim.ParamPool.plan_hyper),
+        None entries while a group's runs are unknown (before its first step) or outside graph mode."""
+        out = {}
+        pool = self._pools[kind]
+        for grp in groups:
+            k0, g = self.shard.local.index(grp[0]), len(grp)
+            h = pool.plan_hyper(k0, g) if self._graph_mode else None
+            out[k0] = None if h is None else self._hin.stage('adam/%s/%d' % (kind, k0), h)
+        return out
+
+    def _opt_key(self, kind):
+        """The optimizer hyper-parameters a captured step bakes into its launches (everything but lr and the step count)."""
+        g = self._pools[kind].opts[0].param_groups[0]
+        return (tuple(g['betas']), g['eps'], g['weight_decay'])
+
+    def _step(self, pool, k0, g, hyper):
+        """Optimizer step of one member group inside a body: launches now, bookkeeping as a replayable effect."""
+        if self._graph_mode:
+            runs = pool.step(k0, g, lockstep=g > 1, hyper=hyper.get(k0), advance=False)
+            if runs is None:
+                if self._recording is not None:
+                    raise hip.HipError("CG_GRAPH=1: the members of a launch diverged (step counts / hyper-parameters)")
+                return
+            self._effect(lambda: pool.advance(k0, g, runs))
+        else:
+            pool.step(k0, g, lockstep=g > 1)
+
     def _const(self, value, n):
         """Device vector of n copies of `value` (upstream gradients of the per-member loss vectors), cached."""
         key = (float(value), n)
@@ -519,53 +655,64 @@ class Council_Trainer(nn.Module):
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}      # source image per direction
         tgt = {'a2b': x['b2a'], 'b2a': x['a2b']}                 # real image of the target domain
         groups = self._plan_groups(x[self._dirs[0]])
+        if self._graph_mode:
+            self._rep_cache.clear()            # the static input buffers hold a new batch: repeat it again (inside the body)
+            self._iter_eager, self._phase = False, 1       # a new iteration starts here (train.py:244-250 call order)
         ctx, tok = self._side_stream(0, x, groups, prologue=True)
-        with ctx, self._fresh_mirrors('gen', 'dis'):
-            pool = self._pools['dis']
-            pool.zero_grad()
+        with ctx:
+            # ---- host part: the reference's RNG draws (trainer_council.py:741,744), staged into static device buffers
             s = {}
             if self.do_a2b_conf:
                 s['a2b'] = self._style(x_b.size(0))
-                self.loss_dis_a2b_s = [0] * self.council_size
             if self.do_b2a_conf:
                 s['b2a'] = self._style(x_a.size(0))
-                self.loss_dis_b2a_s = [0] * self.council_size
-            self.loss_dis_total_s = [0] * self.council_size
-            s_dev = {}
-            self._fork()
-            for grp in groups:
-                g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
-                with self._on(lead, groups), ops.members(g):
-                    losses, ups = [], []
-                    for d in self._dirs:
-                        gen = self._nets('gen', d)[lead]
-                        if (d, g) not in s_dev:
-                            s_dev[(d, g)] = self._upload(s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
-                        xr = self._rep(x[d], g)
-                        content = self._content(d, grp, xr, need_grad=False)
-                        with torch.no_grad(), self._split_decode(d, lead):
-                            x_fake = gen.decode(content, s_dev[(d, g)], xr)
-                        # :775-777 -- only the a2b term is scaled by gan_w (reference quirk, kept): the unscaled loss is what
-                        # train.py logs, the scale rides on the upstream gradient
-                        w = float(hp['gan_w']) if d == 'a2b' else 1.0
-                        l = self._nets('dis', d)[lead].calc_dis_loss(x_fake, tgt[d]).view(-1)       # one loss per member
-                        losses.append(l)
-                        ups.append(self._const(w, g))
-                        for m, i in enumerate(grp):
-                            getattr(self, 'loss_dis_%s_s' % d)[i] = l.detach()[m]
-                    torch.autograd.backward(losses, ups)          # members and directions own disjoint parameters
-                    for m, i in enumerate(grp):
-                        tot = None
-                        for d, l in zip(self._dirs, losses):
-                            w = float(hp['gan_w']) if d == 'a2b' else 1.0
-                            t = l.detach()[m] if w == 1.0 else l.detach()[m] * w
-                            tot = t if tot is None else tot + t
-                        self.loss_dis_total_s[i] = tot
-                    ops.wgrad_join()
-                    self._sync_grads(pool, k0, g)
-                    pool.step(k0, g, lockstep=g > 1)
-            self._join()
+            s_dev = {(d, g): self._hin.stage('dis/s/%s/%d' % (d, g), s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
+                     for d in self._dirs for g in sorted({len(grp) for grp in groups})}
+            hyper = self._stage_hyper('dis', groups)
+            key = ('dis', tuple(x[self._dirs[0]].shape), tuple(map(tuple, groups)), float(hp['gan_w']), self._opt_key('dis'))
+            with self._fresh_mirrors('gen', 'dis'):
+                self._run(key, lambda: self._dis_body(x, tgt, groups, float(hp['gan_w']), s_dev, hyper))
         self._side_done(tok)
+
+    def _dis_body(self, x, tgt, groups, gan_w, s_dev, hyper):
+        """Device work of dis_update (everything below the RNG draws): eager, or captured once and replayed."""
+        pool = self._pools['dis']
+        pool.zero_grad()
+        out = {'loss_dis_total_s': [0] * self.council_size}
+        for d in self._dirs:
+            out['loss_dis_%s_s' % d] = [0] * self.council_size
+        self._fork()
+        for grp in groups:
+            g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
+            with self._on(lead, groups), ops.members(g):
+                losses, ups = [], []
+                for d in self._dirs:
+                    gen = self._nets('gen', d)[lead]
+                    xr = self._rep(x[d], g)
+                    content = self._content(d, grp, xr, need_grad=False)
+                    with torch.no_grad(), self._split_decode(d, lead):
+                        x_fake = gen.decode(content, s_dev[(d, g)], xr)
+                    # :775-777 -- only the a2b term is scaled by gan_w (reference quirk, kept): the unscaled loss is what
+                    # train.py logs, the scale rides on the upstream gradient
+                    w = gan_w if d == 'a2b' else 1.0
+                    l = self._nets('dis', d)[lead].calc_dis_loss(x_fake, tgt[d]).view(-1)       # one loss per member
+                    losses.append(l)
+                    ups.append(self._const(w, g))
+                    for m, i in enumerate(grp):
+                        out['loss_dis_%s_s' % d][i] = l.detach()[m]
+                torch.autograd.backward(losses, ups)          # members and directions own disjoint parameters
+                for m, i in enumerate(grp):
+                    tot = None
+                    for d, l in zip(self._dirs, losses):
+                        w = gan_w if d == 'a2b' else 1.0
+                        t = l.detach()[m] if w == 1.0 else l.detach()[m] * w
+                        tot = t if tot is None else tot + t
+                    out['loss_dis_total_s'][i] = tot
+                ops.wgrad_join()
+                self._sync_grads(pool, k0, g)
+                self._step(pool, k0, g, hyper)
+        self._join()
+        return out
 
     # ------------------------------------------------------------------------------------
     # dis_council_update, trainer_council.py:782-883
@@ -582,86 +729,125 @@ class Council_Trainer(nn.Module):
         if not self.do_council_loss or hp['council_w'] == 0 or hp['iteration'] < c['council_start_at_iter']:
             return
         self._ready()
+        if self._graph_mode and self._phase != 1:      # not right behind this iteration's dis_update: nothing static to build on
+            self._iter_eager = True
+        self._phase = 2
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}
         groups = self._plan_groups(x[self._dirs[0]])
         ctx, tok = self._side_stream(1, x, groups, prologue=False)
-        with ctx, self._fresh_mirrors('gen', 'disc'):
-            pool = self._pools['disc']
-            pool.zero_grad()
-            s, s_less = {}, {}
-            if self.do_b2a_conf:                       # s_a is drawn first here (:806-809)
+        with ctx:
+            # ---- host part: style noise (s_a first, :806-809), then every member's colleague picks (:861-868; every rank
+            # replays every member's draws) -- the two RNG streams are independent, so drawing the picks up front leaves
+            # both sequences as the reference consumes them
+            s = {}
+            if self.do_b2a_conf:
                 s['b2a'] = self._style(x_a.size(0))
             if self.do_a2b_conf:
                 s['a2b'] = self._style(x_b.size(0))
             less = c['discriminetro_less_style_by']
             n_rel = c['numberOfCouncil_dis_relative_iteration']
-            L = len(self.shard.local)
-
-            # ---- every member's translation (full style) and comparison image (reduced style) ------------------------
-            x_full = {d: {} for d in self._dirs}                 # group lead -> the group's own translations [g*B]
-            x_cmp_local = {}
-            for d in self._dirs:
-                b = x[d].shape[0]
-                x_cmp_local[d] = torch.empty((L * b,) + tuple(x[d].shape[1:]), dtype=torch.float32, device=self._device,
-                                             memory_format=torch.channels_last)
-            s_dev = {}
-            self._fork()
-            for grp in groups:
-                g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
-                with self._on(lead, groups), ops.members(g):
-                    for d in self._dirs:
-                        gen = self._nets('gen', d)[lead]
-                        b = x[d].shape[0]
-                        xr = self._rep(x[d], g)
-                        content = self._content(d, grp, xr, need_grad=False)
-                        with torch.no_grad(), self._split_decode(d, lead):
-                            if less != 0:
-                                # the two translations differ only in the style code: one decode over 2B samples per member
-                                # (every operator of the decoder is per sample) -- twice the rows per launch, half the launches
-                                if (d, g) not in s_dev:
-                                    s_dev[(d, g)] = self._upload(torch.cat((s[d], s[d] * less), 0).repeat(g, 1, 1, 1))
-                                twice = [m * b + r for m in range(g) for _ in range(2) for r in range(b)]
-                                both = gen.decode(ops.take_rows(content, None, twice), s_dev[(d, g)], self._rep(x[d], 2 * g))
-                                own = [m * 2 * b + r for m in range(g) for r in range(b)]
-                                x_full[d][lead] = ops.take_rows(both, None, own)
-                                ops.take_rows(both, None, [i + b for i in own], out=x_cmp_local[d][k0 * b:(k0 + g) * b])
-                            else:
-                                if (d, g) not in s_dev:
-                                    s_dev[(d, g)] = self._upload(s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
-                                x_full[d][lead] = gen.decode(content, s_dev[(d, g)], xr)
-                                ops.take_rows(x_full[d][lead], None, list(range(g * b)), out=x_cmp_local[d][k0 * b:(k0 + g) * b])
-            self._join()      # every member's council discriminator reads the OTHER members' images
-            # the ONE cross-member exchange (trainer_council.py:853-856): every member's comparison image, member-major
-            x_cmp = {d: self.shard.exchange_flat(x_cmp_local[d]) for d in self._dirs}
-
-            self.loss_dis_council_a2b_s = [0] * self.council_size
-            self.loss_dis_council_b2a_s = [0] * self.council_size
-            self.loss_dis_council_total_s = [0] * self.council_size
             scale = float(hp['council_w']) / float(n_rel)                      # :878-880
-            picks = [self.draw_colleagues(i, self.council_size, n_rel) for i in range(self.council_size)]   # every rank replays
-            self._fork()                                                                                  # every member's draws
+            picks = [self.draw_colleagues(i, self.council_size, n_rel) for i in range(self.council_size)]
+            sizes = sorted({len(grp) for grp in groups})
+            if less != 0:
+                s_dev = {(d, g): self._hin.stage('disc/s/%s/%d' % (d, g), torch.cat((s[d], s[d] * less), 0).repeat(g, 1, 1, 1))
+                         for d in self._dirs for g in sizes}
+            else:
+                s_dev = {(d, g): self._hin.stage('disc/s/%s/%d' % (d, g), s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
+                         for d in self._dirs for g in sizes}
+            plans = {}
             for grp in groups:
-                g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
+                g, lead = len(grp), grp[0]
                 pk = [[(j, float(picks[i].count(j))) for j in sorted(set(picks[i]))] for i in grp]
-                with self._on(lead, groups), ops.members(g):
-                    losses = []
-                    for d in self._dirs:
-                        l = self._nets('disc', d)[lead].calc_dis_loss_members(
-                            x_full[d][lead], x_cmp[d], pk, x[d], fake_weight=float(len(picks[lead])), weight=scale).view(-1)
-                        losses.append(l)
-                        for m, i in enumerate(grp):
-                            getattr(self, 'loss_dis_council_%s_s' % d)[i] = l.detach()[m] / scale
-                    torch.autograd.backward(losses, [self._const(1.0, g)] * len(losses))
-                    for m, i in enumerate(grp):
-                        tot = None
-                        for l in losses:
-                            tot = l.detach()[m] if tot is None else tot + l.detach()[m]
-                        self.loss_dis_council_total_s[i] = tot
-                    ops.wgrad_join()
-                    self._sync_grads(pool, k0, g)
-                    pool.step(k0, g, lockstep=g > 1)
-            self._join()
+                for d in self._dirs:
+                    b = x[d].shape[0]
+                    idx, idx_in, tgt, wt = MsImageDisCouncil.plan_members(pk, g, b, float(len(picks[lead])), scale)
+                    tag = 'disc/%s/%d/' % (d, lead)
+                    plans[(d, lead)] = (idx, idx_in, self._hin.stage(tag + 'tgt', torch.tensor(tgt, dtype=torch.float32)),
+                                        self._hin.stage(tag + 'wt', torch.tensor(wt, dtype=torch.float32)),
+                                        self._hin.stage(tag + 'idx', torch.tensor(idx, dtype=torch.int32)))
+            hyper = self._stage_hyper('disc', groups)
+            shape = tuple(x[self._dirs[0]].shape)
+            gkey = tuple(map(tuple, groups))
+            u = len(set(picks[0]))
+            with self._fresh_mirrors('gen', 'disc'):
+                # segment 1: every member's translation (full style) and comparison image (reduced style)
+                self._run(('disc1', shape, gkey, float(less)), lambda: self._disc_body_translate(x, groups, less, s_dev))
+                # the ONE cross-member exchange (trainer_council.py:853-856): every member's comparison image, member-major.
+                # Never part of a captured segment: a collective (RCCL, or gloo through the host) runs between two graphs.
+                x_cmp = {d: self._static('cmp/' + d, self.shard.exchange_flat(self._x_cmp_local[d])) for d in self._dirs}
+                # segment 2: the council discriminators on [own | colleagues], backward, Adam
+                self._run(('disc2', shape, gkey, u, scale, self._opt_key('disc')),
+                          lambda: self._disc_body_update(x, x_cmp, groups, plans, scale, hyper))
         self._side_done(tok)
+
+    def _disc_body_translate(self, x, groups, less, s_dev):
+        L = len(self.shard.local)
+        x_full = {d: {} for d in self._dirs}                 # group lead -> the group's own translations [g*B]
+        x_cmp_local = {}
+        for d in self._dirs:
+            b = x[d].shape[0]
+            x_cmp_local[d] = torch.empty((L * b,) + tuple(x[d].shape[1:]), dtype=torch.float32, device=self._device,
+                                         memory_format=torch.channels_last)
+        self._fork()
+        for grp in groups:
+            g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
+            with self._on(lead, groups), ops.members(g):
+                for d in self._dirs:
+                    gen = self._nets('gen', d)[lead]
+                    b = x[d].shape[0]
+                    xr = self._rep(x[d], g)
+                    content = self._content(d, grp, xr, need_grad=False)
+                    with torch.no_grad(), self._split_decode(d, lead):
+                        if less != 0:
+                            # the two translations differ only in the style code: one decode over 2B samples per member
+                            # (every operator of the decoder is per sample) -- twice the rows per launch, half the launches
+                            twice = [m * b + r for m in range(g) for _ in range(2) for r in range(b)]
+                            both = gen.decode(ops.take_rows(content, None, twice), s_dev[(d, g)], self._rep(x[d], 2 * g))
+                            own = [m * 2 * b + r for m in range(g) for r in range(b)]
+                            x_full[d][lead] = ops.take_rows(both, None, own)
+                            ops.take_rows(both, None, [i + b for i in own], out=x_cmp_local[d][k0 * b:(k0 + g) * b])
+                        else:
+                            x_full[d][lead] = gen.decode(content, s_dev[(d, g)], xr)
+                            ops.take_rows(x_full[d][lead], None, list(range(g * b)), out=x_cmp_local[d][k0 * b:(k0 + g) * b])
+        self._join()      # every member's council discriminator reads the OTHER members' images
+        if os.environ.get('CG_DIAG_DBG'):
+            d0 = self._dirs[0]
+            return {'_x_full': x_full, '_x_cmp_local': x_cmp_local,
+                    '_dbg1': {'x_full': x_full[d0][groups[0][0]], 'x_cmp_local': x_cmp_local[d0], 'x': x[d0],
+                              'content': self._content(d0, groups[0], self._rep(x[d0], len(groups[0])), need_grad=False),
+                              's': s_dev[(d0, len(groups[0]))], 'rep2': self._rep(x[d0], 2 * len(groups[0]))}}
+        return {'_x_full': x_full, '_x_cmp_local': x_cmp_local}
+
+    def _disc_body_update(self, x, x_cmp, groups, plans, scale, hyper):
+        pool = self._pools['disc']
+        pool.zero_grad()
+        x_full = self._x_full
+        out = {'loss_dis_council_a2b_s': [0] * self.council_size, 'loss_dis_council_b2a_s': [0] * self.council_size,
+               'loss_dis_council_total_s': [0] * self.council_size}
+        self._fork()
+        for grp in groups:
+            g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
+            with self._on(lead, groups), ops.members(g):
+                losses = []
+                for d in self._dirs:
+                    idx, idx_in, tgt_dev, wt_dev, idx_dev = plans[(d, lead)]
+                    l = self._nets('disc', d)[lead].calc_dis_loss_planned(x_full[d][lead], x_cmp[d], x[d], idx, idx_in,
+                                                                          tgt_dev, wt_dev, idx_dev).view(-1)
+                    losses.append(l)
+                    for m, i in enumerate(grp):
+                        out['loss_dis_council_%s_s' % d][i] = l.detach()[m] / scale
+                torch.autograd.backward(losses, [self._const(1.0, g)] * len(losses))
+                for m, i in enumerate(grp):
+                    tot = None
+                    for l in losses:
+                        tot = l.detach()[m] if tot is None else tot + l.detach()[m]
+                    out['loss_dis_council_total_s'][i] = tot
+                ops.wgrad_join()
+                self._sync_grads(pool, k0, g)
+                self._step(pool, k0, g, hyper)
+        self._join()
+        return out
 
     @staticmethod
     def draw_colleagues(i, council_size, n_rel):
@@ -685,13 +871,14 @@ class Council_Trainer(nn.Module):
         hp = self._hp_last = hyperparameters
         self.hyperparameters = hp
         self._ready()
-        lib = hip.load()
+        if self._graph_mode and self._phase not in (1, 2):
+            self._iter_eager = True
+        self._phase = 0
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}
         groups = self._plan_groups(x[self._dirs[0]])
-        pool = self._pools['gen']
         self._e0 = None                    # the generators are about to change: no side stream may start from the old mark
-        pool.zero_grad()
-        s_a = self._style(x_a.size(0))     # both drawn, s_a first (:284-285)
+        # ---- host part: style noise, both drawn, s_a first (:284-285); schedules (:323-326, 541-555)
+        s_a = self._style(x_a.size(0))
         s_b = self._style(x_b.size(0))
         s = {'a2b': s_b, 'b2a': s_a}
         fl = hp['focus_loss']
@@ -709,18 +896,39 @@ class Council_Trainer(nn.Module):
             self.do_council_loss = False
         council_on = (hp['council_w'] != 0) and self.do_council_loss and self.council_size > 1 and self.do_dis_council
 
+        s_dev = {(d, g): self._hin.stage('gen/s/%s/%d' % (d, g), s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
+                 for d in self._dirs for g in sorted({len(grp) for grp in groups})}
+        pos_dev = {}
+        for grp in groups:                 # loss-matching ring write positions (:518-524, 576-586) of each group's members
+            for d in self._dirs:
+                pos_dev[(d, grp[0])] = self._hin.stage('gen/pos/%s/%d' % (d, grp[0]), torch.tensor(
+                    [self._ring_pos[d][grp[0]], self._ring_pos_c[d][grp[0]]], dtype=torch.int32))
+        hyper = self._stage_hyper('gen', groups)
+        flags = dict(focus_on=bool(focus_on), council_on=bool(council_on), gan_w=float(hp['gan_w']),
+                     council_w=float(hp['council_w']), zo_w=float(hp['mask_zero_or_one_w']), total_w=float(hp['mask_total_w']),
+                     tv_w=float(hp['mask_tv_w']), center=float(fl['mask_zero_or_one_center']),
+                     eps=float(fl['mask_zero_or_one_epsilon']), use_abs=bool(fl['mask_small_use_abs']),
+                     use_square=bool(fl['mask_small_use_square']), match=bool(self.do_w_loss_matching))
+        key = ('gen', tuple(x[self._dirs[0]].shape), tuple(map(tuple, groups)), tuple(sorted(flags.items())), self._opt_key('gen'))
+        with self._fresh_mirrors('gen', 'dis', 'disc'):
+            self._run(key, lambda: self._gen_body(x, groups, flags, s_dev, pos_dev, hyper))
+
+    def _gen_body(self, x, groups, f, s_dev, pos_dev, hyper):
+        lib = hip.load()
+        pool = self._pools['gen']
+        pool.zero_grad()
         C = self.council_size
         ab = {'a2b': 'ab', 'b2a': 'ba'}
-        self.loss_gen_total_s = [0] * C
+        out = {'loss_gen_total_s': [0] * C}
         for d in self._dirs:
-            setattr(self, 'loss_gen_adv_%s_s' % d, [0] * C)
-            setattr(self, 'loss_gen_mask_zero_one_%s_s' % ab[d], [0] * C if focus_on and hp['mask_zero_or_one_w'] != 0 else [])
-            setattr(self, 'loss_gen_mask_total_%s_s' % ab[d], [0] * C)
-            setattr(self, 'loss_gen_mask_TV_%s_s' % ab[d], [0] * C)
-            setattr(self, 'council_loss_%s_s' % ab[d], [0] * C)
+            out['loss_gen_adv_%s_s' % d] = [0] * C
+            out['loss_gen_mask_zero_one_%s_s' % ab[d]] = [0] * C if f['focus_on'] and f['zo_w'] != 0 else []
+            out['loss_gen_mask_total_%s_s' % ab[d]] = [0] * C
+            out['loss_gen_mask_TV_%s_s' % ab[d]] = [0] * C
+            out['council_loss_%s_s' % ab[d]] = [0] * C
         for d in ('a2b', 'b2a'):
             if d not in self._dirs:
-                setattr(self, 'loss_gen_adv_%s_s' % d, [0] * C)
+                out['loss_gen_adv_%s_s' % d] = [0] * C
 
         frozen = []
         for i in self.shard.local:       # no weight gradients for D / council-D in this update
@@ -730,10 +938,7 @@ class Council_Trainer(nn.Module):
                         if p.requires_grad:
                             p.requires_grad_(False)
                             frozen.append(p)
-        s_dev = {}
         n_ring = self._ring_n
-        mirrors = self._fresh_mirrors('gen', 'dis', 'disc')
-        mirrors.__enter__()
         self._fork()
         try:
             for grp in groups:
@@ -742,75 +947,76 @@ class Council_Trainer(nn.Module):
                     roots, ups, totals = [], [], []
                     for d in self._dirs:
                         gen = self._nets('gen', d)[lead]
-                        if (d, g) not in s_dev:
-                            s_dev[(d, g)] = self._upload(s[d].repeat(g, 1, 1, 1) if g > 1 else s[d])
                         xr = self._rep(x[d], g)
-                        x_fake = gen.decode(self._content(d, grp, xr, need_grad=True), s_dev[(d, g)], xr)
+                        content_in = self._content(d, grp, xr, need_grad=True)
+                        x_fake = gen.decode(content_in, s_dev[(d, g)], xr)
                         mask = gen.dec.mask_s
+                        if os.environ.get('CG_DIAG_DBG'):
+                            out.setdefault('_dbg', {}).update({d + '/content': content_in.detach(), d + '/x_fake': x_fake.detach(),
+                                                               d + '/mask': mask.detach(), d + '/s': s_dev[(d, g)], d + '/xr': xr})
                         ftot = adv = lc = w_dev = None
-                        if focus_on:                                                   # :390-451
-                            ftot, parts = ops.focus_loss(mask, fl['mask_zero_or_one_center'], fl['mask_zero_or_one_epsilon'],
-                                                         hp['mask_zero_or_one_w'], hp['mask_total_w'], hp['mask_tv_w'],
-                                                         fl['mask_small_use_abs'], fl['mask_small_use_square'],
+                        if f['focus_on']:                                                   # :390-451
+                            ftot, parts = ops.focus_loss(mask, f['center'], f['eps'], f['zo_w'], f['total_w'], f['tv_w'],
+                                                         f['use_abs'], f['use_square'],
                                                          reduce=self.shard.replica_mean_ if self.shard.dp > 1 else None)
                             roots.append(ftot.view(-1))
                             ups.append(self._const(1.0, g))
                             parts = parts.view(g, 3)
                             for m, i in enumerate(grp):
-                                if hp['mask_zero_or_one_w'] != 0:
-                                    getattr(self, 'loss_gen_mask_zero_one_%s_s' % ab[d])[i] = parts[m, 0]
-                                if hp['mask_total_w'] != 0:
-                                    getattr(self, 'loss_gen_mask_total_%s_s' % ab[d])[i] = parts[m, 1]
-                                if hp['mask_tv_w'] != 0:
-                                    getattr(self, 'loss_gen_mask_TV_%s_s' % ab[d])[i] = parts[m, 2]
+                                if f['zo_w'] != 0:
+                                    out['loss_gen_mask_zero_one_%s_s' % ab[d]][i] = parts[m, 0]
+                                if f['total_w'] != 0:
+                                    out['loss_gen_mask_total_%s_s' % ab[d]][i] = parts[m, 1]
+                                if f['tv_w'] != 0:
+                                    out['loss_gen_mask_TV_%s_s' % ab[d]][i] = parts[m, 2]
                         ring_g, ring_c, w_all = self._rings[d]
                         rg = ring_g[k0 * n_ring:(k0 + g) * n_ring]
                         rc = ring_c[k0 * n_ring:(k0 + g) * n_ring]
-                        if hp['gan_w'] != 0:                                           # :498-529
+                        pd = pos_dev[(d, lead)]
+                        if f['gan_w'] != 0:                                           # :498-529
                             adv = self._nets('dis', d)[lead].calc_gen_loss(x_fake).view(-1)
                             adv_full = self._full_batch(adv)
                             for m, i in enumerate(grp):
-                                getattr(self, 'loss_gen_adv_%s_s' % d)[i] = adv_full[m]
-                            if self.do_w_loss_matching:
-                                check(lib.cg_ring_push_g(ptr(rg), n_ring, self._ring_pos[d][lead], ptr(adv_full), g, stream()),
-                                      "cg_ring_push")
-                                for i in grp:
-                                    self._ring_pos[d][i] += 1
+                                out['loss_gen_adv_%s_s' % d][i] = adv_full[m]
+                            if f['match']:
+                                check(lib.cg_ring_push_dev(ptr(rg), n_ring, ptr(pd[0:1]), ptr(adv_full), g, stream()), "cg_ring_push")
+                                self._effect(lambda d=d, grp=grp: [self._ring_pos[d].__setitem__(i, self._ring_pos[d][i] + 1)
+                                                                   for i in grp])
                             roots.append(adv)
-                            ups.append(self._const(float(hp['gan_w']), g))
-                        if council_on:                                                 # :558-624
+                            ups.append(self._const(f['gan_w'], g))
+                        if f['council_on']:                                                 # :558-624
                             lc = self._nets('disc', d)[lead].calc_gen_loss(x_fake, xr).view(-1)
-                            if self.do_w_loss_matching:
+                            if f['match']:
                                 w_dev = w_all[k0:k0 + g]
-                                check(lib.cg_loss_match_g(ptr(rg), ptr(rc), n_ring, self._ring_pos_c[d][lead],
-                                                          ptr(self._full_batch(lc)), ptr(w_dev), g, stream()), "cg_loss_match")
-                                for i in grp:
-                                    self._ring_pos_c[d][i] += 1
-                                setattr(self, 'w_match_%s_conf' % d, w_dev[0])
+                                check(lib.cg_loss_match_dev(ptr(rg), ptr(rc), n_ring, ptr(pd[1:2]), ptr(self._full_batch(lc)),
+                                                            ptr(w_dev), g, stream()), "cg_loss_match")
+                                self._effect(lambda d=d, grp=grp: [self._ring_pos_c[d].__setitem__(i, self._ring_pos_c[d][i] + 1)
+                                                                   for i in grp])
+                                out['w_match_%s_conf' % d] = w_dev[0]
                         # per-member objective + the upstream gradient of the council term (council_w x matching weight)
                         total, council, gcouncil = ops.gen_total(ftot, adv.detach() if adv is not None else None,
                                                                  lc.detach() if lc is not None else None, w_dev,
-                                                                 hp['gan_w'], hp['council_w'], g)
-                        if council_on:
+                                                                 f['gan_w'], f['council_w'], g)
+                        if f['council_on']:
                             roots.append(lc)
                             ups.append(gcouncil)
                             for m, i in enumerate(grp):
-                                getattr(self, 'council_loss_%s_s' % ab[d])[i] = council[m]
+                                out['council_loss_%s_s' % ab[d]][i] = council[m]
                         totals.append(total)
                     for m, i in enumerate(grp):
                         tot = None
                         for t in totals:
                             tot = t[m] if tot is None else tot + t[m]
-                        self.loss_gen_total_s[i] = tot
+                        out['loss_gen_total_s'][i] = tot
                     torch.autograd.backward(roots, ups)
                     ops.wgrad_join()
                     self._sync_grads(pool, k0, g)
-                    pool.step(k0, g, lockstep=g > 1)
+                    self._step(pool, k0, g, hyper)
         finally:
             self._join()
-            mirrors.__exit__(None, None, None)
             for p in frozen:
                 p.requires_grad_(True)
+        return out
 
     # ------------------------------------------------------------------------------------
     # forward-only paths, trainer_council.py:252-278, 643-733

@@ -397,6 +397,16 @@ int cg_focus_bwd_g(const float* mask, const float* sums, const float* gscale, in
                    float* d_mask, cg_stream_t stream);
 int cg_adam_step_g(float* p, const float* g, float* m, float* v, size_t n, int nmember, long long mstride, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, cg_stream_t stream);
+/* hipGraph-friendly forms: the scalars that change from iteration to iteration come from DEVICE memory, so a captured launch
+ * stays valid when replayed.  cg_adam_hyper (host-only, no launch) computes the two per-step floats exactly as
+ * cg_adam_step_g does; cg_adam_step_dev reads them from hyper_dev[0..1] -- bit-identical to cg_adam_step_g.
+ * cg_ring_push_dev / cg_loss_match_dev read the ring write position from pos_dev[0]. */
+int cg_adam_hyper(float lr, float beta1, float beta2, int step, float* out2_host);
+int cg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, int nmember, long long mstride, float beta1,
+                     float beta2, float eps, float weight_decay, const float* hyper_dev, cg_stream_t stream);
+int cg_ring_push_dev(float* ring, int n, const int32_t* pos_dev, const float* value, int nmember, cg_stream_t stream);
+int cg_loss_match_dev(float* ring_gan, float* ring_council, int n, const int32_t* pos_dev, const float* council_loss,
+                      float* w_out, int nmember, cg_stream_t stream);
 int cg_ring_push_g(float* ring, int n, int pos, const float* value, int nmember, cg_stream_t stream);
 int cg_loss_match_g(float* ring_gan, float* ring_council, int n, int pos, const float* council_loss, float* w_out,
                     int nmember, cg_stream_t stream);

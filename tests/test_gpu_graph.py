@@ -1,0 +1,160 @@
+"""hipGraph mode (CG_GRAPH=1 / cfg['cg_graph'], council-gan_amd/graphs.py): every update's device work is captured once and
+replayed; only the host-derived inputs (style noise, colleague picks, Adam's per-step scalars, the loss-matching ring
+positions) are refreshed per iteration.  The replayed iterations must be BIT-IDENTICAL to the eager ones -- same kernels,
+same launch parameters, same inputs -- and the host must spend a small fraction of the eager enqueue time."""
+import copy
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import parity_util as P
+from oracle import council_oracle as O
+
+pytestmark = pytest.mark.gpu
+CONFIGS = os.path.join(os.path.dirname(__file__), "..", "configs")
+
+
+@pytest.fixture(scope="module")
+def cga():
+    import council_gan_amd
+    council_gan_amd.hip.load()
+    return council_gan_amd
+
+
+def _tiny(name, council, batch):
+    cfg = yaml.safe_load(open(os.path.join(CONFIGS, name)))
+    cfg['gen'].update(dim=16, mlp_dim=32, n_res=2)
+    cfg['dis'].update(dim=16)
+    cfg['council']['council_size'] = council
+    cfg['batch_size'] = batch
+    cfg['iteration'] = 60000
+    return cfg
+
+
+def _run(cga, cfg, graph, iters, size, group_max=None, overlap=None):
+    c = copy.deepcopy(cfg)
+    c['cg_graph'] = '1' if graph else '0'
+    O.seed_all(11)
+    tr = cga.Council_Trainer(c, 'cuda:0')
+    tr.cuda('cuda:0')
+    if group_max is not None:
+        tr._group_max = group_max
+    assert tr._graph_mode == bool(graph)
+    names = ['loss_dis_total_s', 'loss_gen_total_s'] + (['loss_dis_council_total_s', 'council_loss_ab_s', 'council_loss_ba_s']
+                                                        if tr.council_size > 1 else [])
+    rows = []
+    for it in range(iters):
+        O.seed_all(100 + it)                                   # host RNG: style noise + colleague picks of this iteration
+        if it == 0 or not os.environ.get('CG_DIAG_SAME_X'):
+            x_a, x_b = O.synthetic_batch(c['batch_size'], size, seed=7 + it)
+            x_a, x_b = x_a.cuda(), x_b.cuda()
+        c['iteration'] = 60000 + it
+        tr.dis_update(x_a, x_b, c)
+        tr.dis_council_update(x_a, x_b, c)
+        tr.gen_update(x_a, x_b, c, c['iteration'])
+        torch.cuda.synchronize()
+        row = {n: [float(v) for v in getattr(tr, n, [])] for n in names}
+        if os.environ.get('CG_DIAG_DBG'):
+            for k, v in getattr(tr, '_dbg', {}).items():
+                row['dbg.' + k] = [float(v.double().abs().sum())]
+            for k, v in getattr(tr, '_dbg1', {}).items():
+                row['dbg1.' + k] = [float(v.double().abs().sum())]
+        if os.environ.get('CG_DIAG_POOLS'):      # per-pool checksums of weights / gradients / moments (tools/diag_graph.py)
+            for kind, pool in tr._pools.items():
+                for nm in ('data', 'grad', 'm', 'v'):
+                    row['%s.%s' % (kind, nm)] = [float(getattr(pool, nm).double().abs().sum())]
+            if it == int(os.environ.get('CG_DIAG_DUMP_IT', '-1')):
+                row['_dump'] = {'%s/%s/%d/%s' % (d, kind, i, k): p._cg_grad.detach().cpu().clone()
+                                for d in tr._dirs for kind in ('gen',) for i, net in enumerate(tr._nets(kind, d))
+                                for k, p in net.named_parameters() if getattr(p, '_cg_grad', None) is not None}
+        rows.append(row)
+    w = {}
+    for d in tr._dirs:
+        for kind in ('gen', 'dis') + (('disc',) if tr.do_dis_council else ()):
+            for i, net in enumerate(tr._nets(kind, d)):
+                for k, v in net.state_dict().items():
+                    w[(d, kind, i, k)] = v.detach().cpu().clone()
+    steps = [list(o._steps) for o in tr.gen_opt_s]
+    ring = {d: list(tr._ring_pos[d]) for d in tr._dirs}
+    captured = sum(1 for s in tr._segs.values() if s.graph is not None)
+    del tr
+    return rows, w, steps, ring, captured
+
+
+@pytest.mark.parametrize("case", ["m2f_c4_two_groups", "anime_c2_b2a", "bidir_c2"])
+def test_graph_replay_is_bit_identical_to_eager(cga, case):
+    if case == "m2f_c4_two_groups":        # council 4 as two launches of two members: member streams inside the capture
+        cfg, gm = _tiny("male2female_council_folder.yaml", 4, 2), 2
+    elif case == "anime_c2_b2a":
+        cfg, gm = _tiny("anime2face_council_folder.yaml", 2, 2), None
+    else:
+        cfg, gm = _tiny("male2female_council_folder.yaml", 2, 1), None
+        cfg['do_b2a'] = True
+    try:
+        e_rows, e_w, e_steps, e_ring, e_cap = _run(cga, cfg, False, 5, 64, gm)
+        g_rows, g_w, g_steps, g_ring, g_cap = _run(cga, cfg, True, 5, 64, gm)
+    finally:
+        cga.ops.X3_FORWARD = cga.ops.X3_BACKWARD = cga.ops.X3_DYNAMIC_INPUT = True
+    assert e_cap == 0 and g_cap >= 4, (e_cap, g_cap)          # dis, disc1, disc2, gen
+    assert e_rows == g_rows, [(a, b) for a, b in zip(e_rows, g_rows) if a != b][:2]
+    assert e_steps == g_steps and e_ring == g_ring
+    for k in e_w:
+        assert torch.equal(e_w[k], g_w[k]), k
+
+
+def test_graph_mode_recaptures_when_the_schedule_changes(cga):
+    """Crossing focus_loss_start_at_iter / council_start_at_iter changes which kernels an update launches: a new key, a
+    new warm-up + capture; the numbers stay those of the eager run."""
+    cfg = _tiny("male2female_council_folder.yaml", 2, 2)
+    cfg['focus_loss']['focus_loss_start_at_iter'] = 60002
+    try:
+        e_rows, e_w, _, _, _ = _run(cga, cfg, False, 6, 64)
+        g_rows, g_w, _, _, g_cap = _run(cga, cfg, True, 6, 64)
+    finally:
+        cga.ops.X3_FORWARD = cga.ops.X3_BACKWARD = cga.ops.X3_DYNAMIC_INPUT = True
+    assert g_cap >= 5                                        # the generator update was captured under both schedules
+    assert e_rows == g_rows
+    for k in e_w:
+        assert torch.equal(e_w[k], g_w[k]), k
+
+
+def test_graph_mode_host_cost(cga):
+    """The point of the exercise: at full width (male2female 256x256, council 4, batch 1) the host enqueues a replayed
+    iteration in a few milliseconds (eager: ~17 ms of Python + launch calls)."""
+    cfg = yaml.safe_load(open(os.path.join(CONFIGS, "male2female_council_folder.yaml")))
+    cfg['council']['council_size'] = 4
+    cfg['batch_size'] = 1
+    cfg['iteration'] = 60000
+    x_a, x_b = O.synthetic_batch(1, 256)
+    x_a, x_b = x_a.cuda(), x_b.cuda()
+    res = {}
+    try:
+        for graph in (False, True):
+            c = copy.deepcopy(cfg)
+            c['cg_graph'] = '1' if graph else '0'
+            O.seed_all(3)
+            tr = cga.Council_Trainer(c, 'cuda:0')
+            tr.cuda('cuda:0')
+
+            def step():
+                tr.dis_update(x_a, x_b, c); tr.dis_council_update(x_a, x_b, c); tr.gen_update(x_a, x_b, c, 60000)
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            host, total = [], []
+            for _ in range(5):
+                t0 = time.perf_counter(); step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+                host.append(1e3 * (t1 - t0)); total.append(1e3 * (t2 - t0))
+            res[graph] = (float(np.median(host)), float(np.median(total)), [float(v) for v in tr.loss_gen_total_s])
+            del tr
+    finally:
+        cga.ops.X3_FORWARD = cga.ops.X3_BACKWARD = cga.ops.X3_DYNAMIC_INPUT = True
+    print("\n[graph mode] host enqueue per iteration: eager %.1f ms (GPU done after %.1f ms), graph %.1f ms (GPU done after %.1f ms)"
+          % (res[False][0], res[False][1], res[True][0], res[True][1]))
+    assert res[True][2] == res[False][2]
+    assert res[True][0] <= 5.0, res
+    assert res[True][1] <= 1.05 * res[False][1], res
