@@ -321,8 +321,9 @@ def main():
                    "members_per_launch": (len(trainer._groups[1][0]) if trainer._groups else 1),
                    "execution": ("member-batched: the local members' same layer runs as ONE launch (ops.members, "
                                  "optim.ParamPool); discriminator / council-discriminator updates on two side streams: %s; "
-                                 "weight gradients on a companion stream: %s"
-                                 % ("on" if trainer._overlap else "off", "on" if cga.ops.WGRAD_STREAM else "off"))},
+                                 "weight gradients on a companion stream: %s; hipGraph replay of the updates (CG_GRAPH): %s"
+                                 % ("on" if trainer._overlap else "off", "on" if cga.ops.WGRAD_STREAM else "off",
+                                    "on" if trainer._graph_mode else "off"))},
     }
 
     if rank == 0 and world == 1:
@@ -343,6 +344,7 @@ def main():
             # extra leg must not cost the headline number measured above
             streams, trainer._streams = trainer._streams, []     # serialised: a launch's events see only that launch
             overlap, trainer._overlap = trainer._overlap, False  # (no side streams, no companion weight-gradient stream)
+            graph_mode, trainer._graph_mode = trainer._graph_mode, False      # HIP events per launch need eager launches
             wstream, cga.ops.WGRAD_STREAM = cga.ops.WGRAD_STREAM, False
             try:
                 cga.hip.prof_enable(True)
@@ -354,6 +356,7 @@ def main():
             finally:
                 cga.hip.prof_enable(False)
                 trainer._streams, trainer._overlap, cga.ops.WGRAD_STREAM = streams, overlap, wstream
+                trainer._graph_mode = graph_mode
         if prof:
             if args.shape_report:
                 open(args.shape_report, "w").write(cga.hip.prof_report())

@@ -1522,11 +1522,12 @@ static int env_int(const char* name, int dflt) {
 }
 static void tuning_from_env() {
     cg_tuning t{};
-    t.fwd_thin = env_int("CG_FWD_THIN", 0) != 0;
+    t.fwd_thin = env_int("CG_FWD_THIN", 1) != 0;
     t.wgrad_thin = env_int("CG_WGRAD_THIN", 1) != 0;
     const int bm = env_int("CG_WGRAD_X3_BM256", 2);
     t.wgrad_x3_bm256 = (bm == 0 || bm == 1) ? bm : 2;
-    t.wgrad_x3_wide = env_int("CG_WGRAD_X3_WIDE", 0) != 0;
+    const int ww = env_int("CG_WGRAD_X3_WIDE", 2);
+    t.wgrad_x3_wide = (ww == 0 || ww == 1) ? ww : 2;
     t.wgrad_x3_perm = getenv("CG_WGRAD_X3_PERM") != nullptr;
     t.wgrad_legacy = 0;
     t.x3_wide = env_int("CG_X3_WIDE", 16);
@@ -1844,9 +1845,11 @@ struct WgradPlan {
 // measured to win (profiles/r02_i_ab_optin.txt: +15...25 % from 64 such tiles over all members, -4 % below).
 static int wgrad_x3_bm256() { return tune().wgrad_x3_bm256; }
 
-// CG_WGRAD_X3_WIDE=1 / cg_conv2d_wgrad_x3_wide(1): experimental 256 x 256 LDS-DMA tile (conv_wgrad_x3tw_kernel) for layers
-// with Cout % 256 == 0 and C1 % 256 == 0.  Off by default: not yet run on a GPU.
-static bool wgrad_x3_wide() { return tune().wgrad_x3_wide != 0; }
+// CG_WGRAD_X3_WIDE / cg_conv2d_wgrad_x3_wide(): the 256 x 256 LDS-DMA tile (conv_wgrad_x3tw_kernel) for layers with
+// Cout % 256 == 0 and C1 % 256 == 0: 0 = never, 1 = wherever the layer qualifies, unset / 2 = where it was measured to win
+// (profiles/r03_h_ab_wgrad_wide.txt: +6 % on the member-batched res-block shape, +14 % on 256 -> 512 4x4 s2 -- from 32 such
+// tiles over all members; -15 ... -25 % on single-member and 1x1 launches with fewer)
+static int wgrad_x3_wide() { return tune().wgrad_x3_wide; }
 
 WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1, bool x3 = false) {
     // Every instantiated tile has exactly four 32x32 MFMA wave tiles or more (4 waves / block):
@@ -1874,8 +1877,11 @@ WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1, bool x3 = false) {
         if (wgrad_x3_bm256() == 1 || tiles256 >= 64) p.bm = 256;
     }
     if (x3 && wgrad_x3_wide() && CG_X3_INTERLEAVE && p.fast && g->Cout % 256 == 0 && Ct % 256 == 0) {
-        p.bm = 256;
-        p.bn = 256;
+        const long tiles = (long)(g->Cout / 256) * (K / 256) * nmember;
+        if (wgrad_x3_wide() == 1 || tiles >= 32) {
+            p.bm = 256;
+            p.bn = 256;
+        }
     }
     p.tiles_m = (g->Cout + p.bm - 1) / p.bm;
     p.tiles_n = (K + p.bn - 1) / p.bn;
@@ -2344,7 +2350,7 @@ extern "C" int cg_tuning_get(cg_tuning* out) {
 }
 extern "C" int cg_tuning_set(const cg_tuning* in) {
     CG_CHECK_ARG(in != nullptr, "cg_tuning_set: null pointer");
-    CG_CHECK_ARG(in->wgrad_x3_bm256 >= 0 && in->wgrad_x3_bm256 <= 2 && in->tile_rows_scale >= 1 && in->tile_rows_scale <= 64 &&
+    CG_CHECK_ARG(in->wgrad_x3_bm256 >= 0 && in->wgrad_x3_bm256 <= 2 && in->wgrad_x3_wide >= 0 && in->wgrad_x3_wide <= 2 && in->tile_rows_scale >= 1 && in->tile_rows_scale <= 64 &&
                      (in->x3_thin_out == 0 || in->x3_thin_out == 20 || in->x3_thin_out == 21) &&
                      (in->x3_wide == 0 || in->x3_wide == 1 || in->x3_wide == 16 || in->x3_wide == 17),
                  "cg_tuning_set: field out of range");
@@ -2352,9 +2358,9 @@ extern "C" int cg_tuning_set(const cg_tuning* in) {
     return CG_OK;
 }
 // single-field wrappers (A/B tools and tests); each returns the previous setting
-extern "C" int cg_conv2d_wgrad_x3_wide(int on) {        // experimental
+extern "C" int cg_conv2d_wgrad_x3_wide(int mode) {      // 0 / 1 / 2 as CG_WGRAD_X3_WIDE
     const int prev = tune().wgrad_x3_wide;
-    tune().wgrad_x3_wide = on != 0;
+    tune().wgrad_x3_wide = (mode == 0 || mode == 1) ? mode : 2;
     return prev;
 }
 extern "C" int cg_conv2d_wgrad_thin(int on) {           // workspace queries follow it

@@ -360,7 +360,9 @@ __global__ __launch_bounds__(256) void in_bwd_partial_q(const float* __restrict_
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         double* __restrict__ ws, int HW, int C, int S, int rows_per_split,
-                                                        int act, int gs) {
+                                                        int act, int gs, float* __restrict__ mx) {
+    // mx (optional): mx[((n*C + c)*S + s)*2 + {0,1}] = {max |dz|, max |xhat|} over the rows of split s -- what
+    // cg_instnorm_bwd_split needs to bound |dx| before dx exists
     __shared__ double red[256 * 8];
     const int Q = C >> 2, RL = 256 / Q;
     const int qi = threadIdx.x % Q, rl = threadIdx.x / Q;
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(256) void in_bwd_partial_q(const float* __restrict_
     const int r0 = s * rows_per_split, r1 = min(r0 + rows_per_split, HW);
     const size_t base = (size_t)n * HW * C + c;
     double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    float mz[4] = {0.f, 0.f, 0.f, 0.f}, mh[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int r = r0 + rl; r < r1; r += RL) {
         const float4 xv = ld4(x + base + (size_t)r * C), dv = ld4(dy + base + (size_t)r * C);
@@ -380,6 +383,8 @@ __global__ __launch_bounds__(256) void in_bwd_partial_q(const float* __restrict_
             const float dz = in_dz(ds[k], xh, q.g[k], q.b[k], act);
             a[k] += (double)dz;
             b[k] += (double)dz * (double)xh;
+            mz[k] = fmaxf(mz[k], fabsf(dz));
+            mh[k] = fmaxf(mh[k], fabsf(xh));
         }
     }
 #pragma unroll
@@ -400,6 +405,128 @@ __global__ __launch_bounds__(256) void in_bwd_partial_q(const float* __restrict_
             o[0] = sa;
             o[1] = sb;
         }
+    }
+    if (mx) {      // same reduction over the row lanes for the two maxima (floats reuse the LDS array)
+        __syncthreads();
+        float* redf = reinterpret_cast<float*>(red);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            redf[threadIdx.x * 8 + k] = mz[k];
+            redf[threadIdx.x * 8 + 4 + k] = mh[k];
+        }
+        __syncthreads();
+        if (rl == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float sa = 0.f, sb = 0.f;
+                for (int j = 0; j < RL; ++j) {
+                    sa = fmaxf(sa, redf[(j * Q + qi) * 8 + k]);
+                    sb = fmaxf(sb, redf[(j * Q + qi) * 8 + 4 + k]);
+                }
+                float* o = mx + ((size_t)(n * C + c + k) * S + s) * 2;
+                o[0] = sa;
+                o[1] = sb;
+            }
+        }
+    }
+}
+
+// bound[i] >= max |dx| of (sample, channel) i:  |dx| = rstd |gamma| |dz - S1/HW - xhat S2/HW| <= rstd |gamma| (max|dz| + |S1/HW| +
+// max|xhat| |S2/HW|).  One wavefront per (n, c), after in_bwd_final wrote s12.
+__global__ __launch_bounds__(256) void in_bwd_bound(const float* __restrict__ mx, const float* __restrict__ s12,
+                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                    float* __restrict__ bound, int NC, int S, int C, int gs) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= NC) return;
+    const int lane = threadIdx.x & 63;
+    float a = 0.f, b = 0.f;
+    for (int s = lane; s < S; s += 64) {
+        a = fmaxf(a, mx[((size_t)i * S + s) * 2]);
+        b = fmaxf(b, mx[((size_t)i * S + s) * 2 + 1]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a = fmaxf(a, __shfl_xor(a, o, 64));
+        b = fmaxf(b, __shfl_xor(b, o, 64));
+    }
+    if (lane == 0) {
+        const float g = gamma ? fabsf(gamma[(i / C) * gs + (i % C)]) : 1.f;
+        bound[i] = rstd[i] * g * (a + fabsf(s12[i * 2]) + b * fabsf(s12[i * 2 + 1]));
+    }
+}
+
+// dx = rstd * gamma * (dz - S1/HW - xhat * S2/HW) written DIRECTLY as {hi, lo} fp16 planes of scale * dx (interleaved layout,
+// a thread owns a channel octet: two 16-byte stores) -- the form the split-precision data- and weight-gradient kernels of
+// the convolution in front of this norm read.  scale = the power of two that puts max(bound) into [4096, 8192): every
+// block reduces the N*C bounds again (a few KiB from L2).  Optionally dx itself in fp32 too.
+__global__ __launch_bounds__(256) void in_bwd_apply_split_o(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ s12, const float* __restrict__ bound,
+                                                            int NC, float* __restrict__ state, _Float16* __restrict__ out,
+                                                            size_t lo_elems, float* __restrict__ dx, int HW, int C, int act,
+                                                            int gs) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < NC; i += 256) m = fmaxf(m, bound[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const unsigned mb = __float_as_uint(m);
+    const int e8 = (int)((mb >> 23) & 255u);
+    float scale = 1.f;                                  // dyn_scale of conv_x3.inc: 2^(12 - floor(log2 m)); NaN / Inf / 0 -> 1
+    if (e8 != 0 && e8 != 255) {
+        int se = 127 + 12 - (e8 - 127);
+        se = se < 1 ? 1 : (se > 254 ? 254 : se);
+        scale = __uint_as_float((unsigned)se << 23);
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        state[0] = m;
+        state[1] = scale;
+    }
+    const int n = blockIdx.y;
+    const int no = HW * (C >> 3);
+    const int step = gridDim.x * 256;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    const int c = (i % (C >> 3)) << 3;
+    const Quad q0 = load_quad(mean, rstd, gamma, beta, n, C, c, gs), q1 = load_quad(mean, rstd, gamma, beta, n, C, c + 4, gs);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s1[k] = s12[(n * C + c + k) * 2];
+        s2[k] = s12[(n * C + c + k) * 2 + 1];
+    }
+    const size_t base = (size_t)n * HW * C;
+    x += base; dy += base; out += cg_il(base);
+    if (dx) dx += base;
+    for (; i < no; i += step) {
+        const size_t e = 8 * (size_t)i;
+        const float4 x0 = ld4(x + e), x1 = ld4(x + e + 4), d0 = ld4(dy + e), d1 = ld4(dy + e + 4);
+        const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const float ds[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh0 = (xs[k] - q0.m[k]) * q0.r[k], xh1 = (xs[4 + k] - q1.m[k]) * q1.r[k];
+            const float dz0 = in_dz(ds[k], xh0, q0.g[k], q0.b[k], act), dz1 = in_dz(ds[4 + k], xh1, q1.g[k], q1.b[k], act);
+            o[k] = q0.r[k] * q0.g[k] * (dz0 - s1[k] - xh0 * s2[k]);
+            o[4 + k] = q1.r[k] * q1.g[k] * (dz1 - s1[4 + k] - xh1 * s2[4 + k]);
+        }
+        if (dx) {
+            st4(dx + e, make_float4(o[0], o[1], o[2], o[3]));
+            st4(dx + e + 4, make_float4(o[4], o[5], o[6], o[7]));
+        }
+        _Float16 h[8], l[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = o[k] * scale;
+            h[k] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+            l[k] = (_Float16)(v - (float)h[k]);
+        }
+        *reinterpret_cast<uint4*>(out + cg_il(e)) = *reinterpret_cast<const uint4*>(h);
+        *reinterpret_cast<uint4*>(out + lo_elems + cg_il(e)) = *reinterpret_cast<const uint4*>(l);
     }
 }
 
@@ -707,7 +834,7 @@ extern "C" int cg_instnorm_bwd(const float* dy, const float* x, const float* mea
     const bool quad = quad_ok(C) && (size_t)HW * C < (size_t)0x7fffffff;
     if (quad)
         hipLaunchKernelGGL(in_bwd_partial_q, dim3(S, N), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma, beta, part, HW, C,
-                           S, NC_SPLIT_ROWS, act, gstride);
+                           S, NC_SPLIT_ROWS, act, gstride, (float*)nullptr);
     else
         hipLaunchKernelGGL(in_bwd_partial, dim3(cg_div_up(C, 64), N, S), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma,
                            beta, part, HW, C, S, act, gstride);
@@ -731,6 +858,51 @@ extern "C" int cg_instnorm_bwd(const float* dy, const float* x, const float* mea
         hipLaunchKernelGGL(in_bwd_apply, dim3(ew_grid(total)), dim3(256), 0, cg_s(stream), dy, x, mean, rstd, gamma, beta,
                            (const float*)s12, dx, total, HW, C, act, gstride);
     CG_LAUNCH_CHECK("in_bwd_apply");
+    return CG_OK;
+}
+
+// ---- instance-norm backward that hands dx to the split-precision convolution kernels directly ----------------------
+static bool bwd_split_ok(int N, int HW, int C) {
+    return CG_X3_INTERLEAVE && (C & 31) == 0 && (256 % (C >> 3)) == 0 && (size_t)HW * C < (size_t)0x7fffffff && N >= 1;
+}
+extern "C" size_t cg_instnorm_bwd_split_workspace(int N, int HW, int C) {
+    if (N <= 0 || HW <= 0 || C <= 0 || !bwd_split_ok(N, HW, C)) return 0;      // 0: this shape takes cg_instnorm_bwd
+    return cg_instnorm_workspace(N, HW, C) + (size_t)N * C * nc_splits(HW) * 2 * sizeof(float) + (size_t)N * C * sizeof(float);
+}
+extern "C" int cg_instnorm_bwd_split(const float* dy, const float* x, const float* mean, const float* rstd,
+                                     const float* gamma, const float* beta, int gstride, void* dx_split, size_t dx_lo_elems,
+                                     float* state, float* dx, float* dgamma, float* dbeta, int N, int HW, int C, int act,
+                                     void* ws, size_t ws_bytes, cg_stream_t stream) {
+    CG_CHECK_ARG(dy && x && mean && rstd && dx_split && state && N > 0 && HW > 0 && C > 0, "cg_instnorm_bwd_split: bad args");
+    CG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "cg_instnorm_bwd_split: gamma and beta go together");
+    CG_CHECK_ARG(bwd_split_ok(N, HW, C) && dx_lo_elems == CG_X3_LO_ELEMS,
+                 "cg_instnorm_bwd_split: needs the interleaved layout and C %% 32 == 0 (C = %d)", C);
+    if (!ws || ws_bytes < cg_instnorm_bwd_split_workspace(N, HW, C))
+        return cg_set_error(CG_ERR_WORKSPACE, "cg_instnorm_bwd_split: workspace too small");
+    const int S = nc_splits(HW);
+    double* part = (double*)ws;
+    float* s12 = (float*)(part + (size_t)N * C * S * 2);
+    float* mx = s12 + (size_t)N * C * 2;
+    float* bound = mx + (size_t)N * C * S * 2;
+    hipStream_t st = cg_s(stream);
+    hipLaunchKernelGGL(in_bwd_partial_q, dim3(S, N), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, part, HW, C, S,
+                       NC_SPLIT_ROWS, act, gstride, mx);
+    CG_LAUNCH_CHECK("in_bwd_partial_q");
+    hipLaunchKernelGGL(in_bwd_final, dim3(cg_div_up((size_t)N * C, 4)), dim3(256), 0, st, (const double*)part, s12, dgamma,
+                       dbeta, N * C, S, HW, C, gstride);
+    CG_LAUNCH_CHECK("in_bwd_final");
+    hipLaunchKernelGGL(in_bwd_bound, dim3(cg_div_up((size_t)N * C, 4)), dim3(256), 0, st, (const float*)mx, (const float*)s12,
+                       rstd, gamma, bound, N * C, S, C, gstride);
+    CG_LAUNCH_CHECK("in_bwd_bound");
+    const long no = (long)HW * (C >> 3);
+    long b = (no + 256 * 4 - 1) / (256 * 4);
+    const long cap = (2048 + N - 1) / N;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(in_bwd_apply_split_o, dim3((unsigned)b, N), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta,
+                       (const float*)s12, (const float*)bound, N * C, state, (_Float16*)dx_split, dx_lo_elems, dx, HW, C, act,
+                       gstride);
+    CG_LAUNCH_CHECK("in_bwd_apply_split_o");
     return CG_OK;
 }
 

@@ -112,6 +112,9 @@ _SIGS = {
     "cg_instnorm_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "cg_instnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P,
                                 POINTER(c_int), _P]),
+    "cg_instnorm_bwd_split_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "cg_instnorm_bwd_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
+                                      _P, c_size_t, _P]),
     "cg_layernorm_workspace": (c_size_t, [c_int, c_int, c_int]),
     "cg_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
     "cg_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),

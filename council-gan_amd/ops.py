@@ -167,7 +167,7 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x2, weight, bias, wgrad_buf, bgrad_buf, stride, pad, act, up, stats, xsplit=None, wsplit=None,
-                out_split=None, amax_out=None, wmgr=None, wref=None):
+                out_split=None, amax_out=None, wmgr=None, wref=None, dz_split_ok=None):
         # wref = (cg_group or None, the Parameter object): resolved by the caller, where the tensor still carries its
         # Python attributes
         lib = _lib()
@@ -218,6 +218,15 @@ class _Conv2d(torch.autograd.Function):
         ctx.g, ctx.meta = g, (KH, KW, stride, pad, act, int(up), bias is not None)
         ctx.wgrad_buf, ctx.bgrad_buf = wgrad_buf, bgrad_buf
         ctx.grp, ctx.weight, ctx.wmgr, ctx.nm = grp, wparam, wmgr, _G.n      # backward may run outside the members() scope
+        if dz_split_ok is not None and act == 0 and X3_BACKWARD:
+            # Will BOTH gradients of this layer run on the split-precision kernels?  Then the norm behind it may hand its
+            # dx over in split form only (cg_instnorm_bwd_split) -- the same conditions backward() evaluates.
+            need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
+            need_dw = ctx.needs_input_grad[2] or (bias is not None and ctx.needs_input_grad[3])
+            dg = need_dx and g.Cout % 32 == 0 and g.stride <= 2 and (grp is None or (wmgr is not None and wparam is not None))
+            wg = need_dw and ctx.xsplit is not None and bool(lib.cg_conv2d_wgrad_x3_ok_g(byref(g), grp))
+            if (need_dx or need_dw) and (dg or not need_dx) and (wg or not need_dw):
+                dz_split_ok.append(True)
         return y
 
     @staticmethod
@@ -227,6 +236,7 @@ class _Conv2d(torch.autograd.Function):
         KH, KW, stride, pad, act, up, has_bias = ctx.meta
         g, grp = ctx.g, ctx.grp
         amax = getattr(dy, "_cg_amax", None)
+        pre = getattr(dy, "_cg_dz_split", None)      # the norm behind this layer delivered dz in split form ONLY
         dy = nhwc(dy)
         dx = dw = db = None
         # split-precision backward: dz gets a device-side power-of-two scale once, for both gradients
@@ -246,8 +256,14 @@ class _Conv2d(torch.autograd.Function):
                 check(lib.cg_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), act, stream()), "cg_act_bwd")
         else:
             dz = dy
-            if x3_dgrad or x3_wgrad:
+            if pre is not None:
+                if act or fp32_needed:
+                    raise hip.HipError("a gradient delivered in split form only reached a kernel that needs it in fp32")
+                dzs = pre
+            elif x3_dgrad or x3_wgrad:
                 dzs = split_f16_dynamic(dz, amax)
+        if pre is not None and act:
+            raise hip.HipError("a gradient delivered in split form only reached a layer with a fused activation")
         if need_dw:
             if ctx.wgrad_buf is not None:
                 # accumulate straight into the optimizer's flat gradient buffer (optim.py); grouped: every member's slice
@@ -293,7 +309,7 @@ class _Conv2d(torch.autograd.Function):
         dx2 = None
         if x2 is not None and ctx.needs_input_grad[1]:
             dx2 = dgrad(x.shape[1], x2.shape[1])
-        return (dx, dx2, dw, db) + (None,) * 13
+        return (dx, dx2, dw, db) + (None,) * 14
 
 
 # Weight gradients leave the chain of dependent backward kernels: nothing downstream of a layer's backward needs its dW
@@ -359,10 +375,13 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=
     # one's epilogue measure them (stats is None: no instance norm in between)
     amax_out = [] if (X3_FORWARD and X3_DYNAMIC_INPUT and stats is None and out_split is None and weight.dim() == 4 and
                       weight.shape[0] % 32 == 0) else None
+    dz_ok = [] if (stats is not None and X3_BACKWARD and xsplit is not None) else None      # a norm follows
     y = _Conv2d.apply(x, x2, weight, bias, getattr(weight, "_cg_grad", None),
                       getattr(bias, "_cg_grad", None) if bias is not None else None,
                       int(stride), int(pad), ACT[act], bool(upsample), stats, xsplit, wsplit, out_split, amax_out, wmgr,
-                      (_grp(weight), weight))
+                      (_grp(weight), weight), dz_ok)
+    if dz_ok:
+        y._cg_dz_split_ok = True
     if out_split:
         y._cg_split = out_split[0]
     if amax_out:
@@ -388,8 +407,9 @@ class _InstNormAct(torch.autograd.Function):
     of `params` ([N, P], the MLP output, networks.py:303-312) or absent (plain nn.InstanceNorm2d)."""
 
     @staticmethod
-    def forward(ctx, x, params, goff, boff, residual, act, eps, stats, out_split=None):
+    def forward(ctx, x, params, goff, boff, residual, act, eps, stats, out_split=None, dx_split_only=False):
         lib = _lib()
+        ctx.dx_split_only = bool(dx_split_only)
         x, residual = nhwc(x), nhwc(residual)
         N, C, H, W = x.shape
         HW = H * W
@@ -448,16 +468,32 @@ class _InstNormAct(torch.autograd.Function):
         state, nslots = None, ctypes.c_int(0)
         if X3_BACKWARD:
             state = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=x.device)
-        check(lib.cg_instnorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(dx), dgp, dbp, N, HW, C, act,
-                                  ptr(ws), ws.numel(), ptr(state), byref(nslots), stream()), "cg_instnorm_bwd")
-        if nslots.value:
-            dx._cg_amax = (state, nslots.value)     # the conv before this norm splits dx without measuring it again
-        return dx, dparams, None, None, (dy if has_res else None), None, None, None, None
+        wsb = lib.cg_instnorm_bwd_split_workspace(N, HW, C) if (ctx.dx_split_only and X3_BACKWARD and DX_SPLIT) else 0
+        if wsb:
+            # the convolution in front of this norm takes dz in split form for both of its gradients: write the {hi, lo}
+            # planes directly (no fp32 dx, no split pass); `dx` stays an uninitialised carrier of the right shape
+            ws = workspace(wsb)
+            buf = torch.empty(2 * x.numel(), dtype=torch.float16, device=x.device)
+            check(lib.cg_instnorm_bwd_split(ptr(dy), ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(buf), x3_lo(x.numel()),
+                                            ptr(state), None, dgp, dbp, N, HW, C, act, ptr(ws), ws.numel(), stream()),
+                  "cg_instnorm_bwd_split")
+            dx._cg_dz_split = SplitTensor(buf, x.shape, state=state)
+        else:
+            check(lib.cg_instnorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(dx), dgp, dbp, N, HW, C, act,
+                                      ptr(ws), ws.numel(), ptr(state), byref(nslots), stream()), "cg_instnorm_bwd")
+            if nslots.value:
+                dx._cg_amax = (state, nslots.value)     # the conv before this norm splits dx without measuring it again
+        return dx, dparams, None, None, (dy if has_res else None), None, None, None, None, None
+
+
+# CG_DX_SPLIT=0: instance-norm backward always writes fp32 dx and the convolution splits it in a pass of its own (A/B switch)
+DX_SPLIT = os.environ.get("CG_DX_SPLIT", "1") != "0"
 
 
 def _norm_apply(x, params, goff, boff, residual, act, eps, stats, want_split):
     out_split = [] if (want_split and X3_FORWARD) else None
-    y = _InstNormAct.apply(x, params, goff, boff, residual, ACT[act], float(eps), stats, out_split)
+    y = _InstNormAct.apply(x, params, goff, boff, residual, ACT[act], float(eps), stats, out_split,
+                           bool(getattr(x, "_cg_dz_split_ok", False)))
     if out_split:
         y._cg_split = out_split[0]
     return y

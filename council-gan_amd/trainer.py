@@ -273,7 +273,11 @@ class Council_Trainer(nn.Module):
         # per iteration drops from ~17 ms of Python to < 1 ms -- what a rank needs once it holds ONE member (20 ms of GPU
         # work per iteration).  The two discriminator-side updates then stay on the caller's stream (a graph is replayed
         # on one stream); replicated members (gradient all-reduces inside the update) keep the eager path.
-        self._graph_mode = str(self._hp_cfg.get('cg_graph', os.environ.get('CG_GRAPH', '0'))) == '1' and self.shard.dp == 1
+        # Default: on when the council is sharded over several ranks (a rank with one member has ~20 ms of GPU work per
+        # iteration against ~15 ms of eager enqueue), off on a single GPU (GPU-bound either way; eager keeps the overlap of
+        # the two discriminator-side updates: 68.5 vs 69.1 ms per step, profiles/r03_g_*).
+        dflt = '1' if (self.shard.world_size > 1 and self.shard.dp == 1) else '0'
+        self._graph_mode = str(self._hp_cfg.get('cg_graph', os.environ.get('CG_GRAPH', dflt))) == '1' and self.shard.dp == 1
         self._graph_warmup = max(1, int(os.environ.get('CG_GRAPH_WARMUP', '1')))
         self._hin = HostInputs(dev)
         self._segs, self._recording, self._gx = {}, None, {}

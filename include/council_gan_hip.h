@@ -219,10 +219,10 @@ int cg_conv2d_dgrad_g(const cg_conv_geom* g, const cg_group* group, const float*
  * A multi-threaded host sets the table before its first launch.  There is no reference counterpart (the reference
  * leaves algorithm choice to cuDNN, train.py:61 `cudnn.deterministic`). */
 typedef struct cg_tuning {
-    int32_t fwd_thin;        /* CG_FWD_THIN (0): thin-input first layers on the spatial-tile kernel */
+    int32_t fwd_thin;        /* CG_FWD_THIN (1): thin-input first layers on the spatial-tile kernel */
     int32_t wgrad_thin;      /* CG_WGRAD_THIN (1): their weight gradient on conv_wgrad_thin_kernel */
     int32_t wgrad_x3_bm256;  /* CG_WGRAD_X3_BM256 (2): 256 x 128 weight-gradient tile: 0 never, 1 always, 2 where measured to win */
-    int32_t wgrad_x3_wide;   /* CG_WGRAD_X3_WIDE (0): 256 x 256 LDS-DMA weight-gradient tile */
+    int32_t wgrad_x3_wide;   /* CG_WGRAD_X3_WIDE (2): 256 x 256 LDS-DMA weight-gradient tile: 0 never, 1 always, 2 where measured to win */
     int32_t wgrad_x3_perm;   /* CG_WGRAD_X3_PERM (0): v_perm loader instead of the transposing LDS read */
     int32_t wgrad_legacy;    /* (0): non-pipelined fp32 weight-gradient kernel */
     int32_t x3_wide;         /* CG_X3_WIDE (16): wide LDS-DMA forward tile: 0 never, 16 256x256 where it wins, 17 256x128, 1 both */
@@ -243,10 +243,11 @@ int cg_conv2d_wgrad_legacy(int on);
  * 0 = never, 1 = wherever the layer qualifies, 2 (default) = where it was measured to win (>= 64 such tiles over all
  * members).  Returns the previous mode.  Workspace queries follow it. */
 int cg_conv2d_wgrad_x3_bm256(int mode);
-/* EXPERIMENTAL (also CG_WGRAD_X3_WIDE=1; off by default, not yet run on a GPU): 256 x 256 LDS-DMA tile of the split-precision
- * weight gradient for layers with Cout % 256 == 0 and C1 % 256 == 0.  Returns the previous setting. */
-int cg_conv2d_wgrad_x3_wide(int on);
-/* A/B switch (also CG_FWD_THIN=1; off by default): the thin-input layers (3 / 6 / 12 -> 64 channels: the generators' 7x7
+/* 256 x 256 LDS-DMA tile of the split-precision weight gradient for layers with Cout % 256 == 0 and C1 % 256 == 0 (also
+ * CG_WGRAD_X3_WIDE): 0 = never, 1 = wherever the layer qualifies, 2 (default) = from 32 such tiles over all members.
+ * Returns the previous mode.  Workspace queries follow it. */
+int cg_conv2d_wgrad_x3_wide(int mode);
+/* A/B switch (also CG_FWD_THIN=0; on by default since round 3): the thin-input layers (3 / 6 / 12 -> 64 channels: the generators' 7x7
  * and the discriminators' 4x4 stride-2 / two-source 3x3 first convolutions, networks.py:44,152,385-386) on the
  * spatial-tile kernel (tile configuration 40 of cg_conv2d_fwd_tile).  Returns the previous setting. */
 int cg_conv2d_fwd_thin(int on);
@@ -286,6 +287,18 @@ int cg_instnorm_apply(const float* x, const float* mean, const float* rstd, cons
 int cg_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, int gstride, float* dx, float* dgamma, float* dbeta, int N, int HW, int C,
                     int act, void* ws, size_t ws_bytes, float* amax_state, int* amax_nslots, cg_stream_t stream);
+/* The same backward with dx handed over as the {hi, lo} fp16 planes of scale * dx (interleaved layout, dx_lo_elems =
+ * CG_X3_LO_ELEMS) that the split-precision data- / weight-gradient kernels of the convolution IN FRONT of the norm read
+ * (networks.py:515-518: conv -> norm): no fp32 round trip and no separate split pass.  The power-of-two scale is chosen
+ * from an upper bound of max |dx| that the reduction pass yields before dx exists (per (sample, channel): rstd |gamma|
+ * (max|dz| + |S1/HW| + max|xhat| |S2/HW|)) and left in state[1] (state: CG_SPLIT_STATE_FLOATS floats, as
+ * cg_split_f16_dynamic); `dx` (optional) additionally receives the fp32 tensor.  Needs C % 32 == 0;
+ * cg_instnorm_bwd_split_workspace returns 0 for shapes it does not take. */
+size_t cg_instnorm_bwd_split_workspace(int N, int HW, int C);
+int cg_instnorm_bwd_split(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int gstride, void* dx_split, size_t dx_lo_elems, float* state, float* dx,
+                          float* dgamma, float* dbeta, int N, int HW, int C, int act, void* ws, size_t ws_bytes,
+                          cg_stream_t stream);
 /* amax_state / amax_nslots (optional): the apply pass leaves per-block max |dx| in amax_state[2..] and their count in
  * *amax_nslots (0 if it could not) for cg_split_f16_dynamic */
 

@@ -210,6 +210,67 @@ def test_instance_norm(cga, case, affine):
     assert max(errs.values()) < 5e-5, errs
 
 
+@pytest.mark.parametrize("case", [("c64_relu", 2, 64, 16, 16, "relu"), ("c256_none", 3, 256, 16, 8, "none"),
+                                  ("c128_tails", 2, 128, 64, 64, "relu")], ids=lambda c: c[0])
+@pytest.mark.parametrize("affine", [False, True], ids=["in", "adain"])
+def test_instance_norm_backward_in_split_form(cga, case, affine):
+    """cg_instnorm_bwd_split: dx written directly as the {hi, lo} planes of scale * dx, the scale chosen from an upper bound
+    of max |dx| before dx exists.  hi + lo over the scale must be dx to 22 bits, the scaled peak must sit within fp16's
+    range and not more than two binades below the [4096, 8192) window of the exact-maximum scale; dgamma / dbeta unchanged.
+    `c128_tails`: a heavy-tailed upstream gradient (a few spikes 1e4 x the bulk)."""
+    from council_gan_amd import hip, ops
+    _, N, C, H, W, act = case
+    lib = hip.load()
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64) * 2 + 0.7
+    P = 2 * C + 5
+    params = torch.randn(N, P, generator=g, dtype=torch.float64)
+    boff, goff = 3, 3 + C
+    gy = torch.randn(N, C, H, W, generator=g, dtype=torch.float64) * 1e-3
+    if "tails" in case[0]:
+        gy.view(-1)[torch.randint(0, gy.numel(), (20,), generator=g)] *= 1e4
+    xr, pr = x.clone().requires_grad_(True), params.clone().requires_grad_(True)
+    if affine:
+        y = F.batch_norm(xr.view(1, N * C, H, W), None, None, pr[:, goff:goff + C].reshape(-1),
+                         pr[:, boff:boff + C].reshape(-1), True, 0.1, 1e-5).view(N, C, H, W)
+    else:
+        y = F.instance_norm(xr, eps=1e-5)
+    ref_act(y, act).backward(gy)
+    xd, gyd, pd = cl(dev(x)), cl(dev(gy)), dev(params)
+    HW = H * W
+    mean = torch.empty(N * C, device="cuda")
+    rstd = torch.empty_like(mean)
+    ws = hip.workspace(lib.cg_instnorm_workspace(N, HW, C))
+    hip.check(lib.cg_instnorm_stats(hip.ptr(xd), N, HW, C, 1e-5, hip.ptr(mean), hip.ptr(rstd), hip.ptr(ws), ws.numel(),
+                                    hip.stream()), "stats")
+    need = lib.cg_instnorm_bwd_split_workspace(N, HW, C)
+    assert need > 0
+    ws = hip.workspace(need)
+    buf = torch.zeros(2 * xd.numel(), dtype=torch.float16, device="cuda")
+    state = torch.zeros(hip.SPLIT_STATE_FLOATS, device="cuda")
+    dx32 = torch.empty_like(xd)
+    dpar = torch.zeros_like(pd)
+    gp = ops._off(pd, goff) if affine else None
+    bp = ops._off(pd, boff) if affine else None
+    dgp = ops._off(dpar, goff) if affine else None
+    dbp = ops._off(dpar, boff) if affine else None
+    hip.check(lib.cg_instnorm_bwd_split(hip.ptr(gyd), hip.ptr(xd), hip.ptr(mean), hip.ptr(rstd), gp, bp, P if affine else C,
+                                        hip.ptr(buf), ops.x3_lo(xd.numel()), hip.ptr(state), hip.ptr(dx32), dgp, dbp, N, HW, C,
+                                        ops.ACT[act], hip.ptr(ws), ws.numel(), hip.stream()), "cg_instnorm_bwd_split")
+    torch.cuda.synchronize()
+    scale = float(state[1])
+    got = ops.SplitTensor(buf, xd.shape, state=state).to_float().double().cpu() / scale      # physical NHWC order
+    want = xr.grad.permute(0, 2, 3, 1).reshape(-1)
+    peak = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2.0 ** -21 * peak + 1e-12, (float((got - want).abs().max()), peak)
+    assert rel(dx32, xr.grad) < 5e-5
+    assert scale > 0 and np.log2(scale) == round(np.log2(scale))
+    assert 1024.0 <= peak * scale < 8192.0 * 1.0001, (peak, scale, float(state[0]))
+    if affine:
+        assert rel(dpar[:, goff:goff + C], pr.grad[:, goff:goff + C]) < 5e-5
+        assert rel(dpar[:, boff:boff + C], pr.grad[:, boff:boff + C]) < 5e-5
+
+
 def test_layer_norm(cga):
     g = torch.Generator().manual_seed(9)
     N, C, H, W = 3, 16, 9, 7

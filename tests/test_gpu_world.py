@@ -34,7 +34,8 @@ def _cfg(council):
     return cfg
 
 
-def _worker(rank, world, port, council, q, backend="gloo", native=False):
+def _worker(rank, world, port, council, q, backend="gloo", native=False, graph=False, iters=2):
+    os.environ["CG_GRAPH"] = "1" if graph else "0"
     if native:
         os.environ["CG_NATIVE_COLLECTIVES"] = "1"     # the C-ABI communicators instead of torch.distributed's
     import council_gan_amd as cga
@@ -56,7 +57,7 @@ def _worker(rank, world, port, council, q, backend="gloo", native=False):
             x_a, x_b = O.synthetic_batch(4, 64)
             x_a, x_b = x_a.to(dev), x_b.to(dev)
             rows = []
-            for it in range(2):
+            for it in range(iters):
                 O.seed_all(20 + it)
                 tr.dis_update(x_a, x_b, cfg)
                 tr.dis_council_update(x_a, x_b, cfg)
@@ -81,11 +82,11 @@ def _worker(rank, world, port, council, q, backend="gloo", native=False):
             dist.destroy_process_group()
 
 
-def _run(world, council, backend="gloo", native=False):
+def _run(world, council, backend="gloo", native=False, graph=False, iters=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, council, q, backend, native)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, council, q, backend, native, graph, iters)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -121,6 +122,20 @@ def test_sharded_trainer_matches_single_process(world, council):
     for m, vs in wsum.items():
         assert all(v == vs[0] for v in vs), "replicas of member %d diverged" % m
         assert abs(vs[0] - ref[2][m]) <= 1e-3 * max(abs(ref[2][m]), 1.0)
+
+
+def test_sharded_trainer_in_graph_mode():
+    """CG_GRAPH=1 with the council sharded over two ranks: the updates replay as hipGraphs, the image exchange runs eagerly
+    BETWEEN the two segments of the council-discriminator update and lands in a static buffer the second segment reads.
+    Four iterations (eager warm-up, capture, two replays) against the single-process eager run."""
+    ref = _run(1, 4, iters=4)[0]
+    res = _run(2, 4, graph=True, iters=4)
+    for r in res:
+        assert r[1] == res[0][1], "gathered losses differ between ranks"
+    for it in range(4):
+        for got, want in zip(res[0][1][it], ref[1][it]):
+            for g, w in zip(got, want):
+                assert abs(g - w) <= 2e-4 * max(abs(w), 1e-3), (it, got, want)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL transport needs two GPUs (this box has one)")
