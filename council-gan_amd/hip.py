@@ -9,7 +9,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int8, c_int32,
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcouncilgan_hip.so")
+LIB_PATH = os.environ.get("CG_LIB_PATH") or os.path.join(_HERE, "lib", "libcouncilgan_hip.so")      # CG_LIB_PATH: measurement builds (tools/)
 
 ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "tanh": 3}
 MAX_TAPS = 64

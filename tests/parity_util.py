@@ -35,20 +35,34 @@ ACT_TOL = 1e-3
 #   * which elements flip is a lottery: re-running the reference arithmetic itself with every Conv2dBlock output perturbed
 #     by a relative 6e-7 moves its error by 0.8x ... 18x member by member (profiles/r02_gengrad_lottery.txt).
 # Hence, per generator and iteration:
-#   (1) level:      err(ours, fp64) <= max(GEN_GRAD_CAP = 1e-2, GEN_GRAD_FACTOR = 5 x err(fp32 oracle, fp64)) -- an absolute
-#                   cap of 1 % of the gradient norm; the factor (sqrt of the round-off ratio) only matters where the
-#                   reference's own draw is above 2e-3.  (Round 2 used 20 x the oracle's error with no cap: up to 8 %.)
+#   (1) level:      err(ours, fp64) <= max(gen_grad_cap(pixels), GEN_GRAD_FACTOR = 5 x err(fp32 oracle, fp64)) -- an absolute
+#                   cap: 1 % of the gradient norm from 65 536 pixels per member batch up (the benchmark's shape and
+#                   anything larger), 2 % from 16 384, 4 % below -- the EXPECTED flip noise does not depend on the size, its
+#                   spread does: a 128^2 batch-1 step sees a handful of flips, and one with high leverage moves the whole
+#                   gradient (measured: up to 1.3e-2 at 128^2 batch 1, 9e-3 at 64^2, 3e-3 at 256^2).  The factor (sqrt of
+#                   the round-off ratio) only matters where the reference's own draw is above cap / 5.  (Round 2 used
+#                   20 x the oracle's error with no cap: up to 8 %.)
 #   (2) uniformity: no tensor with a non-negligible gradient (>= 1e-4 of the total norm: every weight, every live bias)
 #                   has a relative error above 3 x the overall one once that is above 1e-3 -- flip noise is common to all
 #                   tensors upstream of the flips, a wrong backward kernel shows up in ITS tensors.
 # What pins the backward kernels tensor by tensor is not this band but the smooth tests (tests/test_gpu_parity_targets.py).
 GEN_GRAD_CAP = 1e-2
 GEN_GRAD_FACTOR = 5.0
+# mask_zero_one = mean 1 / (|m - c| + eps), eps = 0.01, amplifies a mask perturbation by up to 1 / eps^2.  Within one iteration
+# it is judged against the fp64 oracle with the reference's own gap as the scale; AFTER an optimizer step (Adam's first step
+# moves every weight by +-lr whatever its gradient's size, so round-off-sized gradients flip signs in any fp32 evaluation)
+# a few 1e-3 of it are noise: 5e-3 relative.
+MASK_ZO_TOL_AFTER_STEP = 5e-3
+
+
+def gen_grad_cap(pixels):
+    """Absolute cap on a generator's l2-relative gradient error vs fp64 for a member batch of `pixels` = B x H x W."""
+    return GEN_GRAD_CAP if pixels >= 65536 else (2 * GEN_GRAD_CAP if pixels >= 16384 else 4 * GEN_GRAD_CAP)
 GEN_GRAD_UNIFORM = 3.0
 GEN_GRAD_MIN_SHARE = 1e-4
 
 
-def check_gen_grad(gs, r32, r64, what, fails=None):
+def check_gen_grad(gs, r32, r64, what, fails=None, pixels=65536):
     """Criteria (1) and (2) for one generator; returns (err ours, err fp32 oracle).  Violations are appended to `fails`
     (or asserted on the spot when there is no list)."""
     keys = list(r64)
@@ -58,8 +72,8 @@ def check_gen_grad(gs, r32, r64, what, fails=None):
         if fails is None:
             raise AssertionError(msg)
         fails.append(msg)
-    if not e_ours <= max(GEN_GRAD_FACTOR * e_ref, GEN_GRAD_CAP):
-        bad(("generator gradient level", what, e_ours, e_ref))
+    if not e_ours <= max(GEN_GRAD_FACTOR * e_ref, gen_grad_cap(pixels)):
+        bad(("generator gradient level", what, e_ours, e_ref, gen_grad_cap(pixels)))
     tot = np.sqrt(sum(float((r64[k].astype(np.float64) ** 2).sum()) for k in keys))
     if e_ours > ACT_TOL:                  # below that the level criterion alone already is the 1e-3 tolerance
         for k in keys:
@@ -206,7 +220,7 @@ def iteration_vs_oracle(cga, cfg, size, batch, seed=1, report=None):
         r64, r32 = g64[key], g32[key]
         assert set(gs) == set(r64), (key, set(gs) ^ set(r64))
         if kind == "gen":
-            e_ours, e_ref = check_gen_grad(gs, r32, r64, key, fails)
+            e_ours, e_ref = check_gen_grad(gs, r32, r64, key, fails, pixels=batch * size * size)
         else:
             e_ours, e_ref = l2rel(gs, r64), l2rel(r32, r64)
             if not e_ours <= ACT_TOL:

@@ -232,7 +232,9 @@ def test_two_iterations_vs_reference(cga, name):
                     # north star: within 1e-3 rel-fp32; where the reference's own fp32-vs-fp64 gap is larger than that
                     # (steep mask head) the measured chaos band of the reference arithmetic
                     import parity_util       # level + per-tensor uniformity, see parity_util.check_gen_grad
-                    parity_util.check_gen_grad({k: gs[k] for k in r64}, ref_full, r64, (it, d, i))
+                    xa = g["x_a"]
+                    parity_util.check_gen_grad({k: gs[k] for k in r64}, ref_full, r64, (it, d, i),
+                                               pixels=int(xa.shape[0] * xa.shape[2] * xa.shape[3]))
                 else:
                     assert e_ours <= ACT_TOL, ("discriminator gradient", kind, it, d, i, e_ours, e_ref)
             # post-step weights: one Adam step moves every weight by <= lr; compare the bulk

@@ -95,7 +95,7 @@ def test_generator_backward_chain_smooth_loss(cga, activ):
     for m in sorted({m for m, _ in worst}):
         mine = {k: v for (mm, k), v in worst.items() if mm == m}
         level = float(np.median(list(mine.values())))
-        assert level <= P.GEN_GRAD_CAP, (m, level)
+        assert level <= P.gen_grad_cap(2 * 64 * 64), (m, level)
         assert max(mine.values()) <= max(P.GEN_GRAD_UNIFORM * level, P.ACT_TOL), (m, level, max(mine, key=mine.get), max(mine.values()))
         assert mine['dec.model.9.conv.weight'] <= P.ACT_TOL and mine['dec.model.9.conv.bias'] <= P.ACT_TOL, mine
 
