@@ -131,9 +131,17 @@ __device__ __forceinline__ void block_amax_store(float vmax, float* __restrict__
         float m = amax_red[0];
 #pragma unroll
         for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, amax_red[w]);
-        const unsigned nb = gridDim.x * gridDim.z, b = blockIdx.z * gridDim.x + blockIdx.x;   // members ride on grid.z
+        // members ride on grid.z, the output-parity classes of a batched data-gradient launch on grid.y
+        const unsigned nb = gridDim.x * gridDim.y * gridDim.z, b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         if (nb <= 1024) state[2 + b] = m;
         else atomicMax(reinterpret_cast<unsigned*>(state + 2 + (b & 1023)), __float_as_uint(m));
+    }
+}
+// a block that has no tile (a class with fewer tiles than the launch's widest) still owns a slot: it reports zero
+__device__ __forceinline__ void block_amax_idle(float* __restrict__ state) {
+    if (threadIdx.x == 0) {
+        const unsigned nb = gridDim.x * gridDim.y * gridDim.z, b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (nb <= 1024) state[2 + b] = 0.f;
     }
 }
 
@@ -1548,6 +1556,7 @@ static cg_tuning& tune() {
 struct FwdAmax {
     float* state = nullptr;
     int nslots = 0;
+    bool all_classes = false;     // a data-gradient launch that carries every output-parity class: multi-class launches report too
 };
 static thread_local FwdAmax fwd_amax;
 constexpr int CG_AMAX_SLOTS_MAX = 1024;     // == CG_AMAX_MAX_SLOTS of conv_x3.inc (state[2 .. 2 + 1024))
@@ -2551,15 +2560,19 @@ extern "C" int cg_conv2d_dgrad_g(const cg_conv_geom* g, const cg_group* group, c
 }
 
 extern "C" int cg_act_bwd_split(const float* dy, const float* y, size_t n, int act, void* out, size_t lo_elems,
-                                float* state, float* dz, cg_stream_t stream) {
-    CG_CHECK_ARG(dy && y && out && state && n > 0 && x3_lo_ok(lo_elems, n * 2), "cg_act_bwd_split: bad args");
+                                float* state, int dy_nslots, float* dz, cg_stream_t stream) {
+    CG_CHECK_ARG(dy && y && out && state && n > 0 && x3_lo_ok(lo_elems, n * 2) && dy_nslots >= 0 && dy_nslots <= CG_AMAX_MAX_SLOTS,
+                 "cg_act_bwd_split: bad args");
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipStream_t st = cg_s(stream);
-    const int nslots = amax_blocks(n);
-    hipLaunchKernelGGL(act_bwd_amax_kernel, dim3(nslots), dim3(256), 0, st, dy, y, dz, n, act, state);
-    CG_LAUNCH_CHECK("act_bwd_amax_kernel");
+    int nslots = dy_nslots;
+    if (nslots <= 0 || dz) {      // nobody measured dy (or the fp32 dz is wanted too): one pass that measures dz itself
+        nslots = amax_blocks(n);
+        hipLaunchKernelGGL(act_bwd_amax_kernel, dim3(nslots), dim3(256), 0, st, dy, y, dz, n, act, state);
+        CG_LAUNCH_CHECK("act_bwd_amax_kernel");
+    }
     hipLaunchKernelGGL(act_bwd_split_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, (_Float16*)out, n, lo_elems, act,
                        state, nslots);
     CG_LAUNCH_CHECK("act_bwd_split_kernel");
@@ -2615,9 +2628,11 @@ extern "C" int cg_conv2d_dgrad_x3_prep(const cg_conv_geom* g, const cg_group* gr
 
 extern "C" int cg_conv2d_dgrad_x3_run(const cg_conv_geom* g, const cg_group* group, const void* dz_split, size_t dz_lo_elems,
                                       const float* dz_scale_dev, const void* wt, float w_scale, const float* w_scale_dev,
-                                      int ci0, int nci, float* dx, cg_stream_t stream) {
+                                      int ci0, int nci, float* dx, float* amax_state, int* amax_nslots, cg_stream_t stream) {
     static thread_local DgradPlan p;
     Grp gr;
+    CG_CHECK_ARG((amax_state == nullptr) == (amax_nslots == nullptr), "cg_conv2d_dgrad_x3_run: amax_state and amax_nslots go together");
+    if (amax_nslots) *amax_nslots = 0;
     int rc = dgrad_x3_checks(g, group, ci0, nci, gr, p, "cg_conv2d_dgrad_x3_run");
     if (rc) return rc;
     CG_CHECK_ARG(dz_split && wt && dx && dz_scale_dev && w_scale > 0.f, "cg_conv2d_dgrad_x3_run: null pointer / bad scale");
@@ -2637,9 +2652,18 @@ extern "C" int cg_conv2d_dgrad_x3_run(const cg_conv_geom* g, const cg_group* gro
     X3Extra ex;
     ex.w_scale_dev = w_scale_dev;
     ex.mb = Members{gr.n, 0, (long long)wt_elems * 4, 0};
-    return launch_x3_cfg(pick_x3_cfg(nci, m_total, g->Cout, p.cg[0].T), b, p.ncls, dz_split, nullptr, dx, (unsigned)(dz_lo_elems * 2),
-                         (unsigned)x3_span(dz_lo_elems, dz_plane), 1.0f / w_scale, dz_scale_dev, cg_s(stream), nullptr, nullptr, 0,
-                         ex);
+    // per-block maxima of dx for whoever splits it next (cg_act_bwd_split): every output-parity class is part of this launch,
+    // so the blocks' maxima cover the whole tensor
+    fwd_amax.state = amax_state;
+    fwd_amax.nslots = 0;
+    fwd_amax.all_classes = true;
+    rc = launch_x3_cfg(pick_x3_cfg(nci, m_total, g->Cout, p.cg[0].T), b, p.ncls, dz_split, nullptr, dx, (unsigned)(dz_lo_elems * 2),
+                       (unsigned)x3_span(dz_lo_elems, dz_plane), 1.0f / w_scale, dz_scale_dev, cg_s(stream), nullptr, nullptr, 0,
+                       ex);
+    if (amax_nslots && !rc) *amax_nslots = fwd_amax.nslots;
+    fwd_amax.state = nullptr;
+    fwd_amax.all_classes = false;
+    return rc;
 }
 
 extern "C" int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, size_t dz_lo_elems,
@@ -2649,7 +2673,8 @@ extern "C" int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, s
         return cg_set_error(CG_ERR_WORKSPACE, "cg_conv2d_dgrad_x3: workspace too small");
     int rc = cg_conv2d_dgrad_x3_prep(g, nullptr, w, ci0, nci, CG_X3_WSCALE, nullptr, ws, ws_bytes, stream);
     if (rc) return rc;
-    return cg_conv2d_dgrad_x3_run(g, nullptr, dz_split, dz_lo_elems, dz_scale_dev, ws, CG_X3_WSCALE, nullptr, ci0, nci, dx, stream);
+    return cg_conv2d_dgrad_x3_run(g, nullptr, dz_split, dz_lo_elems, dz_scale_dev, ws, CG_X3_WSCALE, nullptr, ci0, nci, dx, nullptr,
+                                  nullptr, stream);
 }
 
 extern "C" int cg_x3_interleaved(void) { return CG_X3_INTERLEAVE; }

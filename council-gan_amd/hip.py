@@ -61,7 +61,8 @@ _SIGS = {
     "cg_split_f16_dynamic_capped": (c_int, [_P, _P, c_size_t, c_size_t, _P, c_int, c_float, _P]),
     "cg_conv2d_dgrad_x3_wt_elems": (c_size_t, [POINTER(ConvGeom), c_int]),
     "cg_conv2d_dgrad_x3_prep": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
-    "cg_conv2d_dgrad_x3_run": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_float, _P, c_int, c_int, _P, _P]),
+    "cg_conv2d_dgrad_x3_run": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_float, _P, c_int, c_int, _P, _P,
+                                       POINTER(c_int), _P]),
     "cg_conv2d_wgrad_x3_ok_g": (c_int, [POINTER(ConvGeom), POINTER(Group)]),
     "cg_conv2d_wgrad_x3_g": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_size_t, _P, _P, _P, c_int, _P,
                                      c_size_t, _P]),
@@ -89,7 +90,7 @@ _SIGS = {
     "cg_conv2d_wgrad_x3_ok": (c_int, [POINTER(ConvGeom)]),
     "cg_conv2d_wgrad_x3": (c_int, [POINTER(ConvGeom), _P, c_size_t, _P, _P, c_size_t, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "cg_split_f16_dynamic": (c_int, [_P, _P, c_size_t, c_size_t, _P, c_int, _P]),
-    "cg_act_bwd_split": (c_int, [_P, _P, c_size_t, c_int, _P, c_size_t, _P, _P, _P]),
+    "cg_act_bwd_split": (c_int, [_P, _P, c_size_t, c_int, _P, c_size_t, _P, c_int, _P, _P]),
     "cg_conv2d_dgrad_x3": (c_int, [POINTER(ConvGeom), _P, c_size_t, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "cg_instnorm_apply_split": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, _P]),
     "cg_conv2d_fwd_tile": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, c_int, _P]),

@@ -235,8 +235,14 @@ class _Conv2d(torch.autograd.Function):
         x, x2, w, y = ctx.saved_tensors
         KH, KW, stride, pad, act, up, has_bias = ctx.meta
         g, grp = ctx.g, ctx.grp
+        # maxima / split form a producer attached to THIS gradient tensor: valid only while nobody wrote to it since (the
+        # autograd engine may accumulate another contribution into the same tensor in place: that bumps its version)
         amax = getattr(dy, "_cg_amax", None)
+        if amax is not None and len(amax) == 3:
+            amax = amax[:2] if dy._version == amax[2] else None
         pre = getattr(dy, "_cg_dz_split", None)      # the norm behind this layer delivered dz in split form ONLY
+        if pre is not None and dy._version != getattr(dy, "_cg_dz_version", dy._version):
+            raise hip.HipError("a gradient delivered in split form only was modified in place before its consumer ran")
         dy = nhwc(dy)
         dx = dw = db = None
         # split-precision backward: dz gets a device-side power-of-two scale once, for both gradients
@@ -250,7 +256,7 @@ class _Conv2d(torch.autograd.Function):
         dzs = None
         if act:
             if x3_dgrad or x3_wgrad:
-                dz, dzs = act_bwd_split(dy, y, act, fp32_needed)        # no fp32 round trip of dz when nobody reads it
+                dz, dzs = act_bwd_split(dy, y, act, fp32_needed, amax)  # no fp32 round trip of dz when nobody reads it
             else:
                 dz = torch.empty_like(dy)
                 check(lib.cg_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), act, stream()), "cg_act_bwd")
@@ -478,11 +484,12 @@ class _InstNormAct(torch.autograd.Function):
                                             ptr(state), None, dgp, dbp, N, HW, C, act, ptr(ws), ws.numel(), stream()),
                   "cg_instnorm_bwd_split")
             dx._cg_dz_split = SplitTensor(buf, x.shape, state=state)
+            dx._cg_dz_version = dx._version
         else:
             check(lib.cg_instnorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(dx), dgp, dbp, N, HW, C, act,
                                       ptr(ws), ws.numel(), ptr(state), byref(nslots), stream()), "cg_instnorm_bwd")
             if nslots.value:
-                dx._cg_amax = (state, nslots.value)     # the conv before this norm splits dx without measuring it again
+                dx._cg_amax = (state, nslots.value, dx._version)     # the conv before this norm splits dx without measuring it again
         return dx, dparams, None, None, (dy if has_res else None), None, None, None, None, None
 
 
@@ -740,13 +747,22 @@ def split_f16_dynamic(x, amax=None):
     return SplitTensor(buf, x.shape, state=state)
 
 
-def act_bwd_split(dy, y, act, want_fp32):
-    """dz = dy * act'(y) as a dynamically scaled SplitTensor (+ the fp32 tensor when a non-split kernel still needs it)."""
+# CG_ACT_BWD_AMAX=0: the activation backward always measures dz itself (A/B switch)
+ACT_BWD_AMAX = os.environ.get("CG_ACT_BWD_AMAX", "1") != "0"
+
+
+def act_bwd_split(dy, y, act, want_fp32, amax=None):
+    """dz = dy * act'(y) as a dynamically scaled SplitTensor (+ the fp32 tensor when a non-split kernel still needs it).
+    `amax`: (state, nslots) the producer of dy left behind (the data-gradient kernel of the next layer): its per-block
+    maxima bound |dz| (|act'| <= 1), so the measuring pass over (dy, y) is skipped."""
     buf = torch.empty(2 * dy.numel(), dtype=torch.float16, device=dy.device)
-    state = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=dy.device)
     dz = torch.empty_like(dy) if want_fp32 else None
-    check(_lib().cg_act_bwd_split(ptr(dy), ptr(y), dy.numel(), act, ptr(buf), x3_lo(dy.numel()), ptr(state), ptr(dz), stream()),
-          "cg_act_bwd_split")
+    if amax is not None and not want_fp32 and ACT_BWD_AMAX:
+        state, nslots = amax
+    else:
+        state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=dy.device), 0
+    check(_lib().cg_act_bwd_split(ptr(dy), ptr(y), dy.numel(), act, ptr(buf), x3_lo(dy.numel()), ptr(state), nslots, ptr(dz),
+                                  stream()), "cg_act_bwd_split")
     return dz, SplitTensor(buf, dy.shape, state=state)
 
 
@@ -760,8 +776,14 @@ def conv_dgrad_x3(g, dz, w, ci0, nci, grp=None, weight=None, wmgr=None, nm=1):
     dxl = torch.empty((N, nci, H << up, W << up), dtype=torch.float32, device=dzs.buf.device, memory_format=CL)
     wt = wmgr.dgrad_weights(weight, w, g, ci0, nci, grp, nm) if (wmgr is not None and weight is not None) else None
     if wt is not None:
+        # the kernel leaves the per-block maxima of dx behind: the layer below splits its dz without measuring it again
+        state = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=dxl.device) if not up else None
+        nslots = ctypes.c_int(0)
         check(lib.cg_conv2d_dgrad_x3_run(byref(g), grp, dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), ptr(wt), 1.0, wmgr.scale_ptr(),
-                                         ci0, nci, ptr(dxl), stream()), "cg_conv2d_dgrad_x3_run")
+                                         ci0, nci, ptr(dxl), ptr(state), byref(nslots) if state is not None else None, stream()),
+              "cg_conv2d_dgrad_x3_run")
+        if nslots.value:
+            dxl._cg_amax = (state, nslots.value, dxl._version)
     else:
         if grp is not None:
             raise hip.HipError("member-batched split-precision data gradient needs pool-managed weights")

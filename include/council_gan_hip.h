@@ -149,9 +149,11 @@ int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, f
 int cg_split_f16_dynamic_capped(const float* x, void* out, size_t n, size_t lo_elems, float* state, int nslots,
                                 float max_scale, cg_stream_t stream);
 /* dz = dy * act'(y) straight into split form (cg_act_bwd + cg_split_f16_dynamic without the fp32 round trip); dz
- * (optional) additionally receives the fp32 values */
+ * (optional) additionally receives the fp32 values.  dy_nslots > 0: state[2 .. 2 + dy_nslots) already holds per-block maxima
+ * of dy left by its producer (cg_conv2d_dgrad_x3_run) -- |dz| <= |dy| for relu / lrelu / tanh, so the scale is taken from
+ * them and the measuring pass is skipped (unless dz is wanted in fp32 as well). */
 int cg_act_bwd_split(const float* dy, const float* y, size_t n, int act, void* out, size_t lo_elems, float* state,
-                     float* dz, cg_stream_t stream);
+                     int dy_nslots, float* dz, cg_stream_t stream);
 /* split-precision data gradient (cg_conv2d_dgrad with dz pre-split by cg_split_f16_dynamic; needs Cout % 32 == 0);
  * ws: cg_conv2d_dgrad_workspace(g, nci) bytes (holds the re-laid-out, split weights) */
 int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, size_t dz_lo_elems, const float* dz_scale_dev,
@@ -167,7 +169,7 @@ int cg_conv2d_dgrad_x3_prep(const cg_conv_geom* g, const cg_group* group, const 
                             const float* w_scale_dev, void* wt, size_t wt_bytes, cg_stream_t stream);
 int cg_conv2d_dgrad_x3_run(const cg_conv_geom* g, const cg_group* group, const void* dz_split, size_t dz_lo_elems,
                            const float* dz_scale_dev, const void* wt, float w_scale, const float* w_scale_dev, int ci0,
-                           int nci, float* dx, cg_stream_t stream);
+                           int nci, float* dx, float* amax_state, int* amax_nslots, cg_stream_t stream);
 /* split-precision weight gradient: cg_conv2d_wgrad with x and dz given in {hi, lo} form (+ device-side scales,
  * NULL = 1).  cg_conv2d_wgrad_x3_ok(g) != 0 iff the layer qualifies (one source, every k-tile inside one tap,
  * channel counts multiples of 32, power-of-two output plane); workspace as cg_conv2d_wgrad_workspace(g). */

@@ -48,11 +48,11 @@ ACT_TOL = 1e-3
 # What pins the backward kernels tensor by tensor is not this band but the smooth tests (tests/test_gpu_parity_targets.py).
 GEN_GRAD_CAP = 1e-2
 GEN_GRAD_FACTOR = 5.0
-# mask_zero_one = mean 1 / (|m - c| + eps), eps = 0.01, amplifies a mask perturbation by up to 1 / eps^2.  Within one iteration
-# it is judged against the fp64 oracle with the reference's own gap as the scale; AFTER an optimizer step (Adam's first step
-# moves every weight by +-lr whatever its gradient's size, so round-off-sized gradients flip signs in any fp32 evaluation)
-# a few 1e-3 of it are noise: 5e-3 relative.
-MASK_ZO_TOL_AFTER_STEP = 5e-3
+# mask_zero_one = mean 1 / (|m - c| + eps), eps = 0.01, amplifies a mask perturbation by up to 1 / eps^2 = 1e4: the few pixels
+# whose mask value sits next to c carry the mean, and a forward round-off of 4e-6 on the mask moves them by percents.  The
+# reference's own fp32 value is off its fp64 value by 1e-4 ... 5e-3 member by member (fixture m2f_w64: 8e-4 and 4.7e-3 in
+# ONE run), so the value is judged against the fp64 oracle with max(1e-3, twice the reference's gap, MASK_ZO_TOL = 5e-3).
+MASK_ZO_TOL = 5e-3
 
 
 def gen_grad_cap(pixels):
@@ -206,7 +206,7 @@ def iteration_vs_oracle(cga, cfg, size, batch, seed=1, report=None):
         if len(o32.loss_mask_zero_one[d]):
             mine = lossvec(getattr(tr, 'loss_gen_mask_zero_one_%s_s' % ab))
             r32, r64 = lossvec(o32.loss_mask_zero_one[d]), lossvec(o64.loss_mask_zero_one[d])
-            tol = np.maximum(ACT_TOL * np.abs(r64), 2 * np.abs(r32 - r64)) + 1e-7
+            tol = np.maximum(np.maximum(ACT_TOL, MASK_ZO_TOL) * np.abs(r64), 2 * np.abs(r32 - r64)) + 1e-7
             errs["loss/mask_zero_one_" + d] = float(np.max(np.abs(mine - r64) / np.abs(r64)))
             assert np.all(np.abs(mine - r64) <= tol), ("mask_zero_one", d, mine, r32, r64)
         if cfg['mask_total_w'] != 0 and cfg['iteration'] > cfg['focus_loss']['focus_loss_start_at_iter']:

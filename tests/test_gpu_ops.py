@@ -1012,3 +1012,63 @@ def test_member_batched_losses_and_adam(cga):
     assert np.allclose(gc.cpu().numpy(), [6.0 * a for a in want_w], rtol=1e-6)
     t = ops.take_rows(mask.detach(), outs[0].detach().view(n * 2 * B, 64)[:, :0] if False else None, [3, 0, 5])
     assert torch.equal(t, mask.detach()[[3, 0, 5]])
+
+
+@pytest.mark.parametrize("members", [1, 2])
+def test_activation_backward_takes_its_scale_from_the_data_gradient_kernel(cga, members, monkeypatch):
+    """A stack of stride-2 LeakyReLU convolutions (the discriminators' shape, networks.py:38-46): the data-gradient launch of
+    layer L+1 -- four output-parity classes in one launch -- leaves the per-block maxima of dx behind, and layer L's fused
+    activation-backward + split takes its power-of-two scale from them instead of measuring dz in a pass of its own.
+    Gradients against fp64, with the hand-off on and off, single member and member-batched."""
+    from council_gan_amd import ops, optim
+    torch.manual_seed(3)
+    B = 2
+    convs = [[torch.nn.Conv2d(ci, co, 4, 2) for ci, co in ((32, 64), (64, 128), (128, 128))] for _ in range(members)]
+    opts = [cga.FlatAdam([p for c in cs for p in c.parameters()], lr=1e-4) for cs in convs]
+    pool = optim.ParamPool(opts)
+    pool.materialize('cuda')
+    mgr = ops.SplitWeights(pool)
+    pool.split = mgr
+    x = torch.randn(members * B, 32, 32, 32, dtype=torch.float64)
+    gy = torch.randn(members * B, 128, 4, 4, dtype=torch.float64)
+
+    def ref(m):
+        xr = x[m * B:(m + 1) * B].clone().requires_grad_(True)
+        h = xr
+        ws = []
+        for c in convs[m]:
+            w, b = c.weight.detach().double().cpu().requires_grad_(True), c.bias.detach().double().cpu().requires_grad_(True)
+            ws += [w, b]
+            h = F.leaky_relu(F.conv2d(F.pad(h, (1, 1, 1, 1)), w, b, stride=2), 0.2)
+        h.backward(gy[m * B:(m + 1) * B])
+        return xr.grad, [t.grad for t in ws]
+
+    def run():
+        pool.zero_grad()
+        xd = cl(dev(x)).requires_grad_(True)
+        with ops.members(members):
+            h = xd
+            for c in convs[0]:
+                h = ops.conv2d(h, c.weight, c.bias, 2, 1, 'lrelu', wmgr=mgr)
+            h.backward(cl(dev(gy)))
+        torch.cuda.synchronize()
+        return xd.grad.double().cpu(), [[p._cg_grad.double().cpu().clone() for c in convs[m] for p in c.parameters()]
+                                         for m in range(members)]
+
+    used = []
+    orig = ops.act_bwd_split
+    monkeypatch.setattr(ops, "act_bwd_split", lambda dy, y, act, want, amax=None: (used.append(amax is not None), orig(dy, y, act, want, amax))[1])
+    got = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "ACT_BWD_AMAX", on)
+        used.clear()
+        got[on] = run()
+        if on:
+            assert used.count(True) >= 2, used      # the two lower layers received the maxima of their dy
+    for m in range(members):
+        rx, rw = ref(m)
+        for on in (True, False):
+            gx, gw = got[on]
+            assert rel(gx[m * B:(m + 1) * B], rx) < 2e-5, (on, m, rel(gx[m * B:(m + 1) * B], rx))
+            for a, b in zip(gw[m], rw):
+                assert rel(a, b) < 2e-5, (on, m)
