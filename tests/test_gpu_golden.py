@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity_util as P
 from golden_util import Golden, case_names, rel_err, summary
 from oracle import council_oracle as O
 
