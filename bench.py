@@ -55,6 +55,24 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 F16X3_PEAK_TFLOPS = 2500.0 / 3    # split-precision kernels: dense fp16 MFMA peak / 3 MFMA passes per product
 
 
+def pmc_traffic(kernel):
+    """Counter-derived memory-side traffic of `kernel` on its dominant launch, from the committed PMC record
+    (profiles/pmc_traffic.json: separate rocprofv3 --pmc passes, FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, per launch;
+    tools/pmc_x3w.sh).  Returns (bytes per launch or None, the record or None)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(kernel)
+    except (OSError, ValueError):
+        rec = None
+    if not rec:
+        return None, None
+    try:
+        stamp = open(os.path.join(ROOT, "council-gan_amd", "lib", "libcouncilgan_hip.so.stamp")).read().strip()[:16]
+    except OSError:
+        stamp = None
+    rec = dict(rec, build_stamp_now=stamp, same_build=(stamp is not None and stamp == rec.get("build_stamp")))
+    return rec.get("bytes_per_launch"), rec
+
+
 def kernel_peak(name):
     return F16X3_PEAK_TFLOPS if "_x3" in name else FP32_MFMA_PEAK_TFLOPS
 
@@ -328,9 +346,8 @@ def main():
 
     if rank == 0 and world == 1:
         step_tflops = wmin / (ms_per_step / 1000.0)
-        # traffic: not measured inside this run (PMC counters need rocprofv3 passes of their own); the counter-derived
-        # figure for the dominant kernel on its dominant launch is in profiles/r02_i_x3w_pmc.txt (678.7 MB of memory-side
-        # traffic per member-batched res-block launch against 136.6 MB algorithmic)
+        # traffic: PMC counters need rocprofv3 passes of their own; the JSON carries the committed record of the dominant
+        # kernel on its dominant launch (profiles/pmc_traffic.json, with the build stamp it was taken on)
         roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                 "step_achieved": round(step_tflops, 2),
                 "step_frac": round(step_tflops / (F16X3_PEAK_TFLOPS if trainer._split_fwd else FP32_MFMA_PEAK_TFLOPS), 4),
@@ -369,6 +386,8 @@ def main():
             dom = max(prof.items(), key=lambda kv: kv[1][1])
             dname, (dc, dms, dfl) = dom
             ach = dfl / (dms * 1e-3) / 1e12
+            tbytes, trec = pmc_traffic(dname)
+            roof.update({"traffic": tbytes, "traffic_record": trec})
             roof.update({"kernel": dname, "achieved": round(ach, 2), "peak": round(kernel_peak(dname), 1),
                          "frac": round(ach / kernel_peak(dname), 4),
                          "avg_launch_us": round(1000.0 * dms / dc, 2), "launches_per_step": dc,

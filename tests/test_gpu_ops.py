@@ -814,6 +814,21 @@ def test_device_input_pipeline_matches_reference_transforms(cga):
         cga.DeviceInput('cuda:0', 100, 64)(imgs)
 
 
+def test_device_input_pipeline_matches_the_pil_fixture(cga):
+    """The device input tail against ground truth from an independent implementation: tests/golden/input_pil.npz (flip and
+    crop by PIL, ToTensor / Normalize by NumPy; oracle/make_input_golden.py), bit for bit."""
+    from oracle import input_oracle as IO
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "input_pil.npz"))
+    H, W = int(z["height"]), int(z["width"])
+    Ws = z["images"].shape[2]
+    pipe = cga.DeviceInput('cuda:0', H, W)
+    # RandomCrop draws its window in the FLIPPED image; the kernel crops the original at the mirrored window, then flips
+    crop = np.stack([z["tops"], [IO.window_after_flip(int(l), Ws, W) if f else int(l) for l, f in zip(z["lefts"], z["flips"])]], 1)
+    got = pipe(torch.from_numpy(z["images"]), crop_tl=crop, flip=z["flips"])
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert np.array_equal(got.cpu().numpy(), z["out"])
+
+
 @pytest.mark.parametrize("kind", ["fp32_first_layer", "x3", "x3_too_many_blocks"])
 def test_conv_epilogue_reports_output_maximum(cga, kind):
     """The per-block max|y| a forward convolution can leave behind for the consumer's dynamic split

@@ -319,3 +319,14 @@ def test_bench_refuses_a_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode != 0
+
+
+def test_input_oracle_matches_the_pil_fixture():
+    """SURVEY.md 8f.3 pin: oracle/input_oracle.py against tests/golden/input_pil.npz -- flip and crop done by PIL itself,
+    ToTensor / Normalize by NumPy (oracle/make_input_golden.py), bit for bit."""
+    from oracle import input_oracle as IO
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "input_pil.npz"))
+    H, W = int(z["height"]), int(z["width"])
+    for n in range(len(z["images"])):
+        got = IO.sample(z["images"][n], int(z["tops"][n]), int(z["lefts"][n]), H, W, flip_first=bool(z["flips"][n]))
+        assert got.dtype == torch.float32 and np.array_equal(got.numpy(), z["out"][n]), n
