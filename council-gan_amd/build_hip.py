@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("conv_gemm.hip", "norm.hip", "elementwise.hip", "collective.hip")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("conv_gemm.hip", "norm.hip", "elementwise.hip", "collective.hip", "head.hip")]
 DEPS = SRC + [os.path.join(HERE, "csrc", "cg_common.h"), os.path.join(HERE, "csrc", "conv_x3.inc"), os.path.join(HERE, "..", "include", "council_gan_hip.h")]
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libcouncilgan_hip.so")

@@ -113,6 +113,8 @@ _SIGS = {
     "cg_instnorm_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "cg_instnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P,
                                 POINTER(c_int), _P]),
+    "cg_decoder_head_fwd_x3": (c_int, [_P, c_size_t, _P, _P, _P, c_size_t, c_float, _P, _P, _P, _P, POINTER(Group), _P, _P, _P,
+                                       ctypes.c_longlong, c_int, c_int, c_int, _P]),
     "cg_instnorm_bwd_split_workspace": (c_size_t, [c_int, c_int, c_int]),
     "cg_instnorm_bwd_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                                       _P, c_size_t, _P]),

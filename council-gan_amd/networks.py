@@ -16,7 +16,7 @@ module-by-module execution:
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import hip, ops
 
 
 def _unsupported(what):
@@ -297,7 +297,7 @@ class Decoder_V2_atten(nn.Module):
             i += 3
         return blocks
 
-    def _trunk_split(self, x):
+    def _trunk_split(self, x, want_f32=True):
         """ResBlocks + upsampling convs on the split-precision path (tape-free passes only):
         every 3x3 conv reads {hi, lo} fp16 planes written by the AdaIN apply before it."""
         xs = ops.split_f16(x)
@@ -308,14 +308,28 @@ class Decoder_V2_atten(nn.Module):
         for u in range(self.n_upsample):
             _, zs = conv_block_split(self.model[i + 1], xs, upsample=True)
             last = u + 1 == self.n_upsample
-            x, xs = conv_block_split(self.model[i + 2], zs, want_f32=last)
+            x, xs = conv_block_split(self.model[i + 2], zs, want_f32=last and want_f32)
             i += 3
-        return x, i
+        return x, xs, i
 
     def forward(self, x, im_in, return_mask=False):
         # split-precision trunk: only inside Council_Trainer's tape-free passes, which keep the split weights current
         if self.split_active and not torch.is_grad_enabled() and all(_split_ok(b) for b in self._split_blocks()):
-            y, i = self._trunk_split(x)
+            # tape-free pass: split-precision trunk, then the 1x1 head + mask / blend as ONE kernel reading the trunk's
+            # {hi, lo} planes (ops.decoder_head_x3; the layer-by-layer head below when the fused kernel does not take the shape)
+            head = [self.model[k].conv for k in range(len(self.model) - 3, len(self.model))]
+            wmgr = getattr(self.model[len(self.model) - 1], '_cg_wmgr', None)
+            fused_ok = ops.FUSED_HEAD and wmgr is not None and self.output_dim == 3 and self.num_of_mask_dim_to_add == 3 \
+                and head[0].in_channels == 64 and all(self.model[k].norm is None for k in range(len(self.model) - 3, len(self.model)))
+            y, ys, i = self._trunk_split(x, want_f32=not fused_ok)
+            if fused_ok:
+                out = ops.decoder_head_x3(ys, head, wmgr, im_in, self.output_dim, self.num_of_mask_dim_to_add)
+                if out is None:
+                    raise hip.HipError("fused decoder head refused a shape it was chosen for")
+                new_im, self.mask_s = out
+                if return_mask:
+                    return new_im, self.mask_s
+                return new_im
         else:
             y = self.model[0](x)
             i = 1

@@ -822,6 +822,33 @@ def conv2d_x3(xs, wsplit, Cout, KH, KW, bias=None, stride=1, pad=0, act="none", 
     return y
 
 
+# CG_FUSED_HEAD=0: the decoder's 1x1 head runs layer by layer in the tape-free passes too (A/B switch)
+FUSED_HEAD = os.environ.get("CG_FUSED_HEAD", "1") != "0"
+
+
+def decoder_head_x3(xs, convs, wmgr, im_in, out_dim, nmask):
+    """The decoder's three 1x1 convolutions + mask / blend head (networks.py:393-407) as one kernel, for passes without a tape.
+    xs: SplitTensor of the trunk output; convs: the three nn.Conv2d holders (pool-managed); returns (image, mask) or None when
+    the fused kernel does not take this shape (the caller then runs the layers one by one)."""
+    if not (FUSED_HEAD and x3_interleaved() and xs.state is None and xs.scale == 1.0):
+        return None
+    N, C, H, W = xs.shape
+    if C != 64 or out_dim != 3 or nmask != 3 or [c.out_channels for c in convs] != [64, 64, out_dim * nmask + nmask] or \
+            any(c.kernel_size != (1, 1) or c.in_channels != 64 for c in convs):
+        return None
+    ws = [wmgr.get(c.weight) for c in convs]
+    if any(w is None for w in ws):
+        return None
+    im_in = nhwc(im_in)
+    im_out = empty_nhwc(N, out_dim, H, W, im_in)
+    mask = empty_nhwc(N, nmask, H, W, im_in)
+    check(_lib().cg_decoder_head_fwd_x3(xs.hi_ptr(), xs.lo, ws[0].hi_ptr(), ws[1].hi_ptr(), ws[2].hi_ptr(), x3_lo(1),
+                                        float(ws[0].scale), ws[0].scale_ptr(), ptr(convs[0].bias), ptr(convs[1].bias),
+                                        ptr(convs[2].bias), _grp(convs[0].weight), ptr(im_in), ptr(im_out), ptr(mask),
+                                        N * H * W, C, out_dim, nmask, stream()), "cg_decoder_head_fwd_x3")
+    return im_out, mask
+
+
 def instnorm_split(x, params, goff, boff, act="none", residual=None, eps=1e-5, stats=None, want_f32=False):
     """IN / AdaIN apply (no autograd) whose output is produced in split form (and in fp32 too when `want_f32`:
     the ResBlock skip connection and the fp32 consumers need it).  Returns (y_fp32_or_None, SplitTensor)."""

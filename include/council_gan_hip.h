@@ -289,6 +289,18 @@ int cg_instnorm_apply(const float* x, const float* mean, const float* rstd, cons
 int cg_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, int gstride, float* dx, float* dgamma, float* dbeta, int N, int HW, int C,
                     int act, void* ws, size_t ws_bytes, float* amax_state, int* amax_nslots, cg_stream_t stream);
+/* The decoder's head for passes without a gradient tape, as ONE kernel: the three 1x1 Conv2dBlocks 64 -> 64 (ReLU) -> 64 (ReLU)
+ * -> out_dim * nmask + nmask (tanh) of networks.py:393-395 and the mask / blend head of networks.py:398-407.  xs: the {hi, lo}
+ * planes of the trunk output [npix][channels] (unscaled, as cg_instnorm_apply_split writes them); w7s / w8s / w9s: the layers'
+ * split weights [cout][channels] with their power-of-two scale (w_scale x *w_scale_dev); im_in / im_out / mask: [npix][out_dim
+ * | nmask] fp32.  Split-precision arithmetic as cg_conv2d_fwd_x3; a pixel's channels are read once and nothing but the image
+ * and the mask is written.  `group`: npix covers the members' pixels back to back.  Built for channels = 64, out_dim = 3,
+ * nmask = 3 (every shipped config); other shapes return CG_ERR_ARG and take the layer-by-layer path. */
+int cg_decoder_head_fwd_x3(const void* xs, size_t x_lo_elems, const void* w7s, const void* w8s, const void* w9s,
+                           size_t w_lo_elems, float w_scale, const float* w_scale_dev, const float* b7, const float* b8,
+                           const float* b9, const cg_group* group, const float* im_in, float* im_out, float* mask,
+                           long long npix, int channels, int out_dim, int nmask, cg_stream_t stream);
+
 /* The same backward with dx handed over as the {hi, lo} fp16 planes of scale * dx (interleaved layout, dx_lo_elems =
  * CG_X3_LO_ELEMS) that the split-precision data- / weight-gradient kernels of the convolution IN FRONT of the norm read
  * (networks.py:515-518: conv -> norm): no fp32 round trip and no separate split pass.  The power-of-two scale is chosen

@@ -1087,3 +1087,51 @@ def test_activation_backward_takes_its_scale_from_the_data_gradient_kernel(cga, 
             assert rel(gx[m * B:(m + 1) * B], rx) < 2e-5, (on, m, rel(gx[m * B:(m + 1) * B], rx))
             for a, b in zip(gw[m], rw):
                 assert rel(a, b) < 2e-5, (on, m)
+
+
+@pytest.mark.parametrize("members", [1, 2])
+def test_fused_decoder_head_matches_layer_by_layer(cga, members):
+    """cg_decoder_head_fwd_x3: the decoder's three 1x1 convolutions + mask / blend head (networks.py:393-407) as one kernel,
+    against fp64 (image and mask <= 2e-5 of their range) and against the layer-by-layer split-precision path it replaces in
+    the tape-free passes; a ragged pixel count (not a multiple of the 32-pixel tile), one member and two."""
+    from council_gan_amd import ops, optim
+    torch.manual_seed(5)
+    B, H, W = 2, 17, 13
+    nets = []
+    for _ in range(members):
+        dec = cga.Decoder_V2_atten(2, 1, 256, 3, res_norm='adain', activ='relu', pad_type='zero', num_of_mask_dim_to_add=3)
+        for k in (7, 8, 9):
+            torch.nn.init.kaiming_normal_(dec.model[k].conv.weight)
+            torch.nn.init.normal_(dec.model[k].conv.bias, 0, 0.1)
+        nets.append(dec)
+    opts = [cga.FlatAdam(list(d.parameters()), lr=1e-4) for d in nets]
+    pool = optim.ParamPool(opts)
+    pool.materialize('cuda')
+    mgr = ops.SplitWeights(pool)
+    x = torch.randn(members * B, 64, H, W, dtype=torch.float64)
+    im_in = torch.rand(members * B, 3, H, W, dtype=torch.float64) * 2 - 1
+    xd, imd = cl(dev(x)), cl(dev(im_in))
+    convs = [nets[0].model[k].conv for k in (7, 8, 9)]
+    with torch.no_grad(), ops.members(members):
+        xs = ops.split_f16(xd)
+        got_im, got_mask = ops.decoder_head_x3(xs, convs, mgr, imd, 3, 3)
+        # the path it replaces: three split-precision 1x1 convolutions, then cg_mask_blend_fwd
+        y = xd
+        for k, act in ((7, 'relu'), (8, 'relu'), (9, 'tanh')):
+            c = nets[0].model[k].conv
+            y = ops.conv2d(y, c.weight, c.bias, 1, 0, act, wmgr=mgr)
+        ref_im, ref_mask = ops.mask_blend(y, imd, 3, 3)
+    torch.cuda.synchronize()
+    for m in range(members):
+        h = x[m * B:(m + 1) * B]
+        for k, act in ((7, 'relu'), (8, 'relu'), (9, 'tanh')):
+            c = nets[m].model[k].conv
+            h = F.conv2d(h, c.weight.detach().double().cpu(), c.bias.detach().double().cpu())
+            h = torch.relu(h) if act == 'relu' else torch.tanh(h)
+        mask = (torch.tanh(10 * h[:, 9:12]) + 1) / 2
+        im = im_in[m * B:(m + 1) * B]
+        for j in range(3):
+            im = (1 - mask[:, j:j + 1]) * im + mask[:, j:j + 1] * h[:, 3 * j:3 * j + 3]
+        sl = slice(m * B, (m + 1) * B)
+        assert rel(got_im[sl], im) < 2e-5 and rel(got_mask[sl], mask) < 2e-5, (m, rel(got_im[sl], im), rel(got_mask[sl], mask))
+    assert rel(got_im, ref_im.double().cpu()) < 2e-5 and rel(got_mask, ref_mask.double().cpu()) < 2e-5
