@@ -1856,8 +1856,9 @@ static int wgrad_x3_bm256() { return tune().wgrad_x3_bm256; }
 
 // CG_WGRAD_X3_WIDE / cg_conv2d_wgrad_x3_wide(): the 256 x 256 LDS-DMA tile (conv_wgrad_x3tw_kernel) for layers with
 // Cout % 256 == 0 and C1 % 256 == 0: 0 = never, 1 = wherever the layer qualifies, unset / 2 = where it was measured to win
-// (profiles/r03_h_ab_wgrad_wide.txt: +6 % on the member-batched res-block shape, +14 % on 256 -> 512 4x4 s2 -- from 32 such
-// tiles over all members; -15 ... -25 % on single-member and 1x1 launches with fewer)
+// (profiles/r03_h_ab_wgrad_wide.txt, with one block per CU's worth of splits: +14 % on the member-batched res-block shape,
+// +16 % on 256 -> 512 4x4 s2, +20 % on 512 -> 512 1x1 against the best of the other tiles, reduce included -- from 16 such
+// tiles over all members; -5 % on a single member's res-block launch with 9)
 static int wgrad_x3_wide() { return tune().wgrad_x3_wide; }
 
 WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1, bool x3 = false) {
@@ -1887,7 +1888,7 @@ WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1, bool x3 = false) {
     }
     if (x3 && wgrad_x3_wide() && CG_X3_INTERLEAVE && p.fast && g->Cout % 256 == 0 && Ct % 256 == 0) {
         const long tiles = (long)(g->Cout / 256) * (K / 256) * nmember;
-        if (wgrad_x3_wide() == 1 || tiles >= 32) {
+        if (wgrad_x3_wide() == 1 || tiles >= 16) {
             p.bm = 256;
             p.bn = 256;
         }
@@ -1897,7 +1898,8 @@ WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1, bool x3 = false) {
     const int slices = (M + 31) / 32;
     const int tiles = p.tiles_m * p.tiles_n * nmember;
     int want = (2 * 256) / tiles;                      // two co-resident blocks per CU, and no partial second round
-    if (want < 1) want = 1;
+    if (p.bm == 256 && p.bn == 256) want = 256 / tiles;   // the 256 x 256 LDS-DMA tile: one block per CU (136 KiB of LDS) -- and
+    if (want < 1) want = 1;                               // half the partial sums for the reduce kernel to add up
     if (K <= 128 && g->Cout <= 128) want *= 4;         // 1x1-class gradients are bandwidth-bound: more loads in flight
     int max_by_work = slices / 8 > 0 ? slices / 8 : 1; // >= 8 slices (256 positions) per split
     int s = want < max_by_work ? want : max_by_work;

@@ -144,6 +144,10 @@ __global__ __launch_bounds__(256) void head_fwd_x3_kernel(HeadArgs a) {
     const long long ntiles = (npm + 31) / 32;
     const _Float16* xs = reinterpret_cast<const _Float16*>(a.xs);
     for (long long t = (long long)blockIdx.x * 4 + wid; t < ntiles; t += (long long)gridDim.x * 4) {
+        // the weight fragments are re-read from LDS for every tile: hoisted out of this loop they would occupy 160 VGPRs and
+        // leave ONE wave per SIMD with nothing to hide the pixel loads behind (measured: 400 us for a 268 MB launch); the
+        // reads cost 320 LDS cycles per tile
+        asm volatile("" ::: "memory");
         const long long pm = t * 32 + l31;                         // pixel inside the member
         const bool live = pm < npm;
         const long long p = (long long)z * npm + (live ? pm : npm - 1);        // clamp: dead lanes read a valid pixel

@@ -246,7 +246,7 @@ int cg_conv2d_wgrad_legacy(int on);
  * members).  Returns the previous mode.  Workspace queries follow it. */
 int cg_conv2d_wgrad_x3_bm256(int mode);
 /* 256 x 256 LDS-DMA tile of the split-precision weight gradient for layers with Cout % 256 == 0 and C1 % 256 == 0 (also
- * CG_WGRAD_X3_WIDE): 0 = never, 1 = wherever the layer qualifies, 2 (default) = from 32 such tiles over all members.
+ * CG_WGRAD_X3_WIDE): 0 = never, 1 = wherever the layer qualifies, 2 (default) = from 16 such tiles over all members.
  * Returns the previous mode.  Workspace queries follow it. */
 int cg_conv2d_wgrad_x3_wide(int mode);
 /* A/B switch (also CG_FWD_THIN=0; on by default since round 3): the thin-input layers (3 / 6 / 12 -> 64 channels: the generators' 7x7
