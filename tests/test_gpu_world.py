@@ -181,3 +181,24 @@ def test_single_rank_communicator_of_the_c_abi():
             comm.all_gather(torch.empty(3, device="cuda"), y.view(-1))
     finally:
         comm.close()
+
+
+def test_bench_launches_its_ranks_on_the_gpu_box(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command): two ranks start, rendezvous on 127.0.0.1,
+    shard council 4 two members each, run real training steps (both share this box's one GPU; gloo carries the exchange) in
+    hipGraph mode -- the default of a sharded run -- and rank 0 prints ONE JSON line with n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = dict(os.environ, CG_DIST_BACKEND="gloo", CG_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CG_GRAPH"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--batch", "1",
+                        "--size", "128"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0
+    assert out["config"]["members_per_gpu"] == 2 and "hipGraph replay of the updates (CG_GRAPH): on" in out["config"]["execution"]
