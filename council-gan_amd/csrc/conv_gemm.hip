@@ -1541,7 +1541,8 @@ static void tuning_from_env() {
     t.x3_wide = env_int("CG_X3_WIDE", 16);
     const int to = env_int("CG_X3_THIN_OUT", 20);
     t.x3_thin_out = (to == 20 || to == 21) ? to : 0;
-    t.x3_korder = env_int("CG_X3_KORDER", 0) != 0;
+    const int ko = env_int("CG_X3_KORDER", 0);
+    t.x3_korder = ko < 0 ? 0 : (ko > 2 ? 2 : ko);
     t.tile_rows_scale = env_int("CG_TILE_ROWS_SCALE", 1) < 1 ? 1 : env_int("CG_TILE_ROWS_SCALE", 1);
     t.no_amax_atomic = getenv("CG_NO_AMAX_ATOMIC") != nullptr;
     g_tune = t;
@@ -2089,7 +2090,7 @@ static int conv2d_fwd_x3_impl(const cg_conv_geom* g, const cg_group* group, cons
     fill_class(b.c[0], g, (const float*)ws, gr.n);
     b.c[0].w_bytes = (unsigned)(w_lo_elems * 2);
     b.c[0].pad_ = (int32_t)w_span;
-    const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, (long)Mm * gr.n, g->C1, g->T) : tile_cfg;
+    const int cfg = tile_cfg < 0 ? pick_x3_cfg(g->Cout, (long)Mm * gr.n, g->C1, g->up ? 1 : g->T) : tile_cfg;
     CG_CHECK_ARG((cfg != 6 && cfg != 7) || g->C1 % 64 == 0, "%s: tile configuration %d needs C %% 64 == 0", who, cfg);
     const int bm = x3_cfg_bm(cfg);
     double* st_ptr = nullptr;
@@ -2362,7 +2363,7 @@ extern "C" int cg_tuning_get(cg_tuning* out) {
 extern "C" int cg_tuning_set(const cg_tuning* in) {
     CG_CHECK_ARG(in != nullptr, "cg_tuning_set: null pointer");
     CG_CHECK_ARG(in->wgrad_x3_bm256 >= 0 && in->wgrad_x3_bm256 <= 2 && in->wgrad_x3_wide >= 0 && in->wgrad_x3_wide <= 2 && in->tile_rows_scale >= 1 && in->tile_rows_scale <= 64 &&
-                     (in->x3_thin_out == 0 || in->x3_thin_out == 20 || in->x3_thin_out == 21) &&
+                     (in->x3_thin_out == 0 || in->x3_thin_out == 20 || in->x3_thin_out == 21) && in->x3_korder >= 0 && in->x3_korder <= 2 &&
                      (in->x3_wide == 0 || in->x3_wide == 1 || in->x3_wide == 16 || in->x3_wide == 17),
                  "cg_tuning_set: field out of range");
     tune() = *in;
