@@ -1545,6 +1545,7 @@ static void tuning_from_env() {
     t.x3_korder = ko < 0 ? 0 : (ko > 2 ? 2 : ko);
     t.tile_rows_scale = env_int("CG_TILE_ROWS_SCALE", 1) < 1 ? 1 : env_int("CG_TILE_ROWS_SCALE", 1);
     t.no_amax_atomic = getenv("CG_NO_AMAX_ATOMIC") != nullptr;
+    t.wgrad_x3_multitap = env_int("CG_WGRAD_X3_MULTITAP", 1) != 0;
     g_tune = t;
 }
 static cg_tuning& tune() {
@@ -1883,6 +1884,12 @@ WgradPlan plan_wgrad(const cg_conv_geom* g, int nmember = 1, bool x3 = false) {
         while (p.bn < 128 && p.bn < K) p.bn <<= 1;
         if (p.bn > 128) p.bn = 128;
     }
+    // split-precision plans on the transposing-read kernel: a K-tile may span several taps (every 32-channel group of the tile
+    // carries its own tap), so layers with 32 / 64 input channels take 128-wide tiles too -- twice / four times the MFMAs per
+    // staged dz row (profiles/r03_p_ab_wgrad_multitap.txt); columns past K read zeros and are not written
+    if (x3 && tune().wgrad_x3_multitap && CG_X3_INTERLEAVE && !tune().wgrad_x3_perm && p.fast && p.bn < 128 &&
+        (Ct == 32 || Ct == 64) && K >= 128)
+        p.bn = 128;
     if (x3 && wgrad_x3_bm256() && CG_X3_INTERLEAVE && p.fast && p.bm == 128 && p.bn == 128 && g->Cout % 256 == 0) {
         const long tiles256 = (long)(g->Cout / 256) * ((K + 127) / 128) * nmember;
         if (wgrad_x3_bm256() == 1 || tiles256 >= 64) p.bm = 256;

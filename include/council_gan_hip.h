@@ -234,7 +234,8 @@ typedef struct cg_tuning {
     int32_t tile_rows_scale; /* CG_TILE_ROWS_SCALE (1): TEST HOOK -- choose tiles as if a launch had k x its rows, so that a
                               * batch-1 parity run exercises the tiles the batch-k benchmark selects */
     int32_t no_amax_atomic;  /* CG_NO_AMAX_ATOMIC (0): launches with > 1024 blocks do not report output maxima */
-    int32_t reserved[5];
+    int32_t wgrad_x3_multitap; /* CG_WGRAD_X3_MULTITAP (1): 128-wide K-tiles spanning several taps for 32 / 64 input channels */
+    int32_t reserved[4];
 } cg_tuning;
 int cg_tuning_get(cg_tuning* out);
 int cg_tuning_set(const cg_tuning* in);

@@ -722,7 +722,9 @@ def _wgrad_tile_case(cga, shape, switch, restore):
     members = [1] + ([3] if N % 3 == 0 else [2])
     prev = switch(lib, False)
     try:
-        base = {n: run(n) for n in members}
+        # (a layer may qualify for the split-precision weight gradient only WITH the switch on: then there is no baseline)
+        has_base = bool(lib.cg_conv2d_wgrad_x3_ok_g(byref(geom), byref(hip.Group(1, 0, 0))))
+        base = {n: run(n) for n in members} if has_base else None
         switch(lib, True)
         wide = {n: run(n) for n in members}
     finally:
@@ -731,9 +733,10 @@ def _wgrad_tile_case(cga, shape, switch, restore):
         per = N // n
         for m in range(n):
             rw, rb = ref(m * per, (m + 1) * per)
-            for got in (base[n][m], wide[n][m]):
+            for got in ((base[n][m], wide[n][m]) if has_base else (wide[n][m],)):
                 assert rel(got[0], rw) < 2e-5 and rel(got[1], rb) < 2e-5, (n, m, rel(got[0], rw), rel(got[1], rb))
-            assert rel(wide[n][m][0], base[n][m][0]) < 2e-6
+            if has_base:
+                assert rel(wide[n][m][0], base[n][m][0]) < 2e-6
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27])
@@ -1135,3 +1138,26 @@ def test_fused_decoder_head_matches_layer_by_layer(cga, members):
         sl = slice(m * B, (m + 1) * B)
         assert rel(got_im[sl], im) < 2e-5 and rel(got_mask[sl], mask) < 2e-5, (m, rel(got_im[sl], im), rel(got_mask[sl], mask))
     assert rel(got_im, ref_im.double().cpu()) < 2e-5 and rel(got_mask, ref_mask.double().cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(4, 32, 32, 64, 128, 4, 2, 1), (4, 16, 8, 64, 64, 3, 1, 1), (2, 16, 16, 32, 128, 3, 1, 1),
+                                   (4, 16, 16, 64, 128, 1, 1, 0)],
+                         ids=["4x4s2_64to128", "3x3_64to64_K576_tail", "3x3_32to128", "1x1_64to128_K64_not_taken"])
+def test_split_precision_weight_gradient_multi_tap_tiles(cga, shape):
+    """conv_wgrad_x3t_kernel with K-tiles that span several taps (cg_tuning.wgrad_x3_multitap): layers with 32 / 64 input
+    channels on 128-wide tiles -- every 32-channel group of a tile carries its own tap, columns past K = T * Cin read zeros.
+    Against fp64 and against the one-tap-per-tile plan, weight + bias gradient, one member and member-batched."""
+    from council_gan_amd import hip
+
+    def switch(lib, on):
+        t = hip.tuning()
+        prev = t.wgrad_x3_multitap
+        t.wgrad_x3_multitap = 1 if on else 0
+        hip.check(lib.cg_tuning_set(t), "cg_tuning_set")
+        return prev
+
+    def restore(lib, prev):
+        t = hip.tuning()
+        t.wgrad_x3_multitap = prev
+        hip.check(lib.cg_tuning_set(t), "cg_tuning_set")
+    _wgrad_tile_case(cga, shape, switch, restore)

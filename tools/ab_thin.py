@@ -111,6 +111,41 @@ def thin_output(lib):
         print("%-34s | %s | max diff %.1e" % (name, " | ".join(res), d), flush=True)
 
 
+def wgrad_multitap(lib):
+    print("== split-precision weight gradient, 32 / 64 input channels: one tap per K-tile (64-wide) | K-tiles spanning taps (128-wide), incl. the reduce")
+    shapes = [("D 64->128 4x4s2 @256 b32 (4 members)", 32, 256, 64, 128, 4, 2, 1, 4), ("D 64->128 4x4s2 @128 b32 (4 members)", 32, 128, 64, 128, 4, 2, 1, 4),
+              ("DC 64->128 4x4s2 @256 b64 (4 members)", 64, 256, 64, 128, 4, 2, 1, 4), ("G 64->128 4x4s2 @256 b16 (4 members)", 16, 256, 64, 128, 4, 2, 1, 4),
+              ("dec 64->64 3x3 @256 b16 (4 members)", 16, 256, 64, 64, 3, 1, 1, 4)]
+    for name, N, HW, Cin, Cout, K, stride, pad, nm in shapes:
+        g = ops.fwd_geom(N, HW, HW, Cin, 0, 0, K, K, stride, pad, Cout, 0)
+        x = torch.randn(N, Cin, HW, HW, device="cuda").contiguous(memory_format=CL)
+        dz = (torch.randn(N, Cout, g.Ho, g.Wo, device="cuda") * 1e-3).contiguous(memory_format=CL)
+        nw = Cout * Cin * K * K
+        stride_el = ((nw + Cout + 31) // 32) * 32
+        flat = torch.zeros(nm * stride_el, device="cuda")
+        grp = hip.Group(nm, 0, stride_el)
+        res, outs = [], []
+        with torch.no_grad():
+            xs, dzs = ops.split_f16_dynamic(x), ops.split_f16_dynamic(dz)
+            for on in (0, 1):
+                t = hip.tuning(); prev = t.wgrad_x3_multitap; t.wgrad_x3_multitap = on; lib.cg_tuning_set(byref(t))
+                try:
+                    wsb = hip.workspace(lib.cg_conv2d_wgrad_workspace_g(byref(g), byref(grp)))
+
+                    def run():
+                        hip.check(lib.cg_conv2d_wgrad_x3_g(byref(g), byref(grp), xs.hi_ptr(), xs.lo, xs.scale_ptr(), dzs.hi_ptr(),
+                                                           dzs.lo, dzs.scale_ptr(), hip.ptr(flat[:nw]), hip.ptr(flat[nw:]), 0,
+                                                           hip.ptr(wsb), wsb.numel(), hip.stream()), "wgrad")
+                    ms = timed(run, 5)
+                    outs.append(flat.clone())
+                finally:
+                    t = hip.tuning(); t.wgrad_x3_multitap = prev; lib.cg_tuning_set(byref(t))
+                fl = 2.0 * N * g.Ho * g.Wo * Cout * Cin * K * K
+                res.append("%7.1f us %6.1f TF" % (ms * 1000, fl / ms / 1e9))
+        d = float((outs[0] - outs[1]).abs().max() / outs[0].abs().max())
+        print("%-40s | %s | %s | max rel diff %.1e" % (name, res[0], res[1], d), flush=True)
+
+
 def wgrad_256(lib):
     print("== split-precision weight gradient: 128x128 / 8 waves | 256x128 / 16 waves | 256x256 LDS-DMA / 8 waves (experimental), incl. the reduce")
     shapes = [("res 256->256 3x3 @64 b16 (4 members)", 16, 64, 256, 256, 3, 1, 1, 4),
@@ -152,6 +187,9 @@ def wgrad_256(lib):
 
 if __name__ == "__main__":
     lib = hip.load()
+    if sys.argv[1:2] == ["multitap"]:
+        wgrad_multitap(lib)
+        sys.exit(0)
     which = sys.argv[1:] or ["thin", "thinw", "out", "wgrad"]
     if "thin" in which:
         thin_forward(lib)
