@@ -85,10 +85,12 @@ def _run(cga, cfg, graph, iters, size, group_max=None, overlap=None):
     return rows, w, steps, ring, captured
 
 
-@pytest.mark.parametrize("case", ["m2f_c4_two_groups", "anime_c2_b2a", "bidir_c2"])
+@pytest.mark.parametrize("case", ["m2f_c4_two_groups", "m2f_c2_one_by_one", "anime_c2_b2a", "bidir_c2"])
 def test_graph_replay_is_bit_identical_to_eager(cga, case):
     if case == "m2f_c4_two_groups":        # council 4 as two launches of two members: member streams inside the capture
         cfg, gm = _tiny("male2female_council_folder.yaml", 4, 2), 2
+    elif case == "m2f_c2_one_by_one":      # one member per launch (what a rank with ONE member runs): the single-member Adam path
+        cfg, gm = _tiny("male2female_council_folder.yaml", 2, 2), 1
     elif case == "anime_c2_b2a":
         cfg, gm = _tiny("anime2face_council_folder.yaml", 2, 2), None
     else:
