@@ -292,6 +292,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if trainer._graph_mode:
+        # hipGraph mode: one eager pass and the captures are setup work (like building the model), not warm-up steps of a
+        # replaying job -- run them before the W warm-up steps so that W = 0 or 1 still times replays only
+        for it in range(trainer._graph_warmup + 1):
+            step(-(trainer._graph_warmup + 1) + it)
     elapsed = time_steps(step, fence, args.warmup, args.steps)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")

@@ -532,7 +532,9 @@ class Council_Trainer(nn.Module):
                     gc_was_on = gc.isenabled()
                     gc.disable()
                     try:
-                        with torch.cuda.graph(g, stream=cap):
+                        # CG_GRAPH_CAPTURE_MODE: torch.cuda.graph's capture_error_mode ("global" by default; "thread_local" /
+                        # "relaxed" if another thread of the host -- a collective library's watchdog -- must call HIP meanwhile)
+                        with torch.cuda.graph(g, stream=cap, capture_error_mode=os.environ.get('CG_GRAPH_CAPTURE_MODE', 'global')):
                             seg.out = body()
                         seg.effects = self._recording
                     finally:
