@@ -532,9 +532,10 @@ class Council_Trainer(nn.Module):
                     gc_was_on = gc.isenabled()
                     gc.disable()
                     try:
-                        # CG_GRAPH_CAPTURE_MODE: torch.cuda.graph's capture_error_mode ("global" by default; "thread_local" /
-                        # "relaxed" if another thread of the host -- a collective library's watchdog -- must call HIP meanwhile)
-                        with torch.cuda.graph(g, stream=cap, capture_error_mode=os.environ.get('CG_GRAPH_CAPTURE_MODE', 'global')):
+                        # capture_error_mode "thread_local": only the capturing thread is policed.  Under "global" (torch's
+                        # default) a potentially-unsafe HIP call from ANY thread invalidates the capture -- and the
+                        # collective library's watchdog thread polls hipEventQuery on the image exchange it has just run
+                        with torch.cuda.graph(g, stream=cap, capture_error_mode=os.environ.get('CG_GRAPH_CAPTURE_MODE', 'thread_local')):
                             seg.out = body()
                         seg.effects = self._recording
                     finally:
