@@ -4,7 +4,12 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-rocprofv3 --kernel-trace --stats -d $O/raw -o bench -- python $R/bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > $O/bench.json 2> $O/bench.err
+# PROF_TOOL="tools/one_member_rank.py --graph 1 --steps 10": profile that tool instead of bench.py
+if [ -n "${PROF_TOOL:-}" ]; then
+  rocprofv3 --kernel-trace --stats -d $O/raw -o bench -- python $R/$PROF_TOOL > $O/bench.json 2> $O/bench.err
+else
+  rocprofv3 --kernel-trace --stats -d $O/raw -o bench -- python $R/bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > $O/bench.json 2> $O/bench.err
+fi
 DB=$(find $O/raw -name "*.db" | head -1)
 python $R/tools/rocpd_summary.py $DB 70 > $O/kernel_stats.txt 2>&1
 python $R/tools/rocpd_timeline.py $DB 0.4 > $O/timeline.txt 2>&1
