@@ -443,6 +443,17 @@ def main():
         peak = (F16X3_PEAK_TFLOPS if trainer._split_fwd else FP32_MFMA_PEAK_TFLOPS) * world
         step_tflops = wmin / (ms_per_step / 1000.0)
         out["rccl_ranks"] = dist.get_world_size()
+        # the same configuration on ONE GPU, from the committed record of this round (this run cannot measure it): what the
+        # ">= 6x at 8 GPUs over 1 GPU" target divides by when N = 8 runs council 8
+        try:
+            rec = os.path.join(ROOT, "profiles", "r03_final_bench_cfg%d.json" % (args.cfg or 3))
+            one = json.loads(open(rec).read().strip().splitlines()[-1])
+            if one.get("n_gpus") == 1 and one["config"].get("preset") == out["config"]["preset"]:
+                out["n1_same_config"] = {"value": one["value"], "ms_per_step": one["ms_per_step"], "source": os.path.relpath(rec, ROOT),
+                                         "speedup": round(value / one["value"], 3),
+                                         "note": "committed single-GPU record of this configuration, a different box and day"}
+        except (OSError, ValueError, KeyError):
+            pass
         out["collective_backend"] = dist.get_backend() + (" (native C-ABI communicators)" if trainer.shard.slice_comm is not None else "")
         out["rccl_version"] = rccl_version() if dist.get_backend() == "nccl" else None
         out["roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": round(peak, 1), "traffic": None,
