@@ -152,7 +152,13 @@ def wgrad_256(lib):
               ("res 256->256 3x3 @64 b4 (1 member)", 4, 64, 256, 256, 3, 1, 1, 1),
               ("128->256 4x4s2 @128 b16 (4 members)", 16, 128, 128, 256, 4, 2, 1, 4),
               ("256->512 4x4s2 @64 b64 (4 members)", 64, 64, 256, 512, 4, 2, 1, 4),
-              ("512->512 1x1 @32 b64 (4 members)", 64, 32, 512, 512, 1, 1, 0, 4)]
+              ("512->512 1x1 @32 b64 (4 members)", 64, 32, 512, 512, 1, 1, 0, 4),
+              # one member per rank (tools/one_member_rank.py): a discriminator sees 20 images, the generator 4
+              ("res 256->256 3x3 @64 b8 (1 member)", 8, 64, 256, 256, 3, 1, 1, 1),
+              ("128->256 4x4s2 @128 b20 (1 member)", 20, 128, 128, 256, 4, 2, 1, 1),
+              ("256->512 4x4s2 @64 b20 (1 member)", 20, 64, 256, 512, 4, 2, 1, 1),
+              ("256->512 4x4s2 @32 b20 (1 member)", 20, 32, 256, 512, 4, 2, 1, 1),
+              ("256->128 3x3 @128 b4 (1 member)", 4, 128, 256, 128, 3, 1, 1, 1)]
     wide_too = "wide" in sys.argv[1:]
     for name, N, HW, Cin, Cout, K, stride, pad, nm in shapes:
         g = ops.fwd_geom(N, HW, HW, Cin, 0, 0, K, K, stride, pad, Cout, 0)
