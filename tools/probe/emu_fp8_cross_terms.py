@@ -2,7 +2,8 @@
 
 Today a.b ~ ah.bh + ah.bl + al.bh with all four planes fp16 (3 fp16 MFMA passes, 22 significand bits).  The cross terms are
 2^-11 of the main term, so their operands need only a few bits: evaluate them as fp8 (e4m3) MFMAs -- twice the fp16 rate on
-gfx950 -- and the product costs 1 + 2/2 = 2 fp16-pass equivalents instead of 3.  This script emulates that on a res-block
+gfx950 -- and the product costs 1 + 2/2 = 2 fp16-pass equivalents instead of 3 (block-scaled fp6 / fp4 run at four times
+the fp16 rate: 1.5 pass equivalents).  This script emulates that on a res-block
 sized convolution in float64 arithmetic with quantised operands and prints the error against the exact fp64 result next to
 plain fp32, fp16 x 3 and single-pass fp16.
 
@@ -35,6 +36,32 @@ def q8(t, target=256.0):
     return (t * s).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float32).to(D) / s
 
 
+def mx(t, cdim, kind):
+    """OCP microscaling along the contraction (channel) dimension: blocks of 32 channels share one power-of-two scale
+    (e8m0), elements are fp6 e2m3 (max 7.5, step 1/8 below 2) or fp4 e2m1 (max 6: 0, .5, 1, 1.5, 2, 3, 4, 6) or fp8 e4m3."""
+    t = t.movedim(cdim, -1)
+    shp = t.shape
+    b = t.reshape(-1, shp[-1] // 32, 32)
+    m = b.abs().amax(-1, keepdim=True).clamp_min(1e-300)
+    emax = {"fp6": 2, "fp4": 2, "fp8": 8}[kind]
+    s = torch.exp2(torch.floor(torch.log2(m)) - emax)
+    v = b / s
+    if kind == "fp8":
+        q = v.clamp(-448, 448).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float32).to(D)
+    else:
+        a = v.abs()
+        if kind == "fp6":
+            a = a.clamp_max(7.5)
+            e = torch.floor(torch.log2(a.clamp_min(1.0)))          # 0, 1, 2 (sub-normals share exponent 0)
+            step = torch.exp2(e - 3)
+        else:
+            a = a.clamp_max(6.0)
+            e = torch.floor(torch.log2(a.clamp_min(1.0)))
+            step = torch.exp2(e - 1)
+        q = torch.round(a / step) * step * torch.sign(v)
+    return (q * s).reshape(shp).movedim(-1, cdim)
+
+
 def conv(a, b):
     return F.conv2d(a, b, padding=1)
 
@@ -62,6 +89,9 @@ def main():
         rows.append(("fp16 x 3 (shipped)", conv(xh, wh) + conv(xh, wl) + conv(xl, wh)))
         rows.append(("fp16 main + fp8 cross terms", conv(xh, wh) + conv(q8(xh), q8(wl)) + conv(q8(xl), q8(wh))))
         rows.append(("fp16 x 2 (one operand unsplit: ah.bh + al.bh)", conv(xh, wh) + conv(xl, wh)))
+        for kind in ("fp8", "fp6", "fp4"):
+            rows.append(("fp16 main + MX-%s cross terms (32-channel blocks)" % kind,
+                         conv(xh, wh) + conv(mx(xh, 1, kind), mx(wl, 1, kind)) + conv(mx(xl, 1, kind), mx(wh, 1, kind))))
         print("== %s" % name)
         for label, y in rows:
             e = err(y, ref)

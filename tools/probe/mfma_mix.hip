@@ -1,0 +1,99 @@
+// Matrix-pipe issue rate of the split-precision product under three operand plans, registers only (no memory traffic):
+//   A  fp16 x 3 (shipped):            per 64-deep K slab of a 32x32 tile: 12 x v_mfma_f32_32x32x16_f16
+//   B  fp16 main + fp8 cross terms:    4 x ..._f16  +  2 x v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 e4m3 x fp8 e4m3)
+//   C  fp16 main + fp6 cross terms:    4 x ..._f16  +  2 x v_mfma_scale_f32_32x32x64_f8f6f4 (fp6 e2m3 x fp6 e2m3)
+//   D  fp16 only (1 pass):             4 x ..._f16                      -- the ceiling
+// Every wave owns TILES independent accumulators (the wide convolution kernel's wave owns 8) and walks them product-major,
+// WAVES waves per block, one block per CU.  Prints "product TFLOP/s" = 2*32*32*64 flops per slab and tile / time: the
+// rate at which a.b products complete, whatever the number of MFMA passes behind each.
+// Build + run:  hipcc --offload-arch=gfx950 -O2 tools/probe/mfma_mix.hip -o gpurun_out/mfma_mix && gpurun_out/mfma_mix
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef int i8v __attribute__((ext_vector_type(8)));
+
+constexpr int TILES = 8;
+
+template <int MODE>
+__global__ __launch_bounds__(512) void mix_kernel(float* out, int slabs, float seed) {
+    f16v acc[TILES];
+    for (int t = 0; t < TILES; ++t)
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    h8 a[4], b[2];
+    for (int i = 0; i < 8; ++i) {
+        for (int k = 0; k < 4; ++k) a[k][i] = (_Float16)(seed + threadIdx.x * 1e-3f + k + i);
+        for (int k = 0; k < 2; ++k) b[k][i] = (_Float16)(seed - threadIdx.x * 1e-3f + k - i);
+    }
+    i8v qa[4], qb[2];
+    for (int i = 0; i < 8; ++i) {
+        for (int k = 0; k < 4; ++k) qa[k][i] = 0x38383838 + (int)threadIdx.x + k + i;     // fp8 1.0-ish bytes
+        for (int k = 0; k < 2; ++k) qb[k][i] = 0x38383838 - (int)threadIdx.x - k - i;
+    }
+    for (int s = 0; s < slabs; ++s) {
+        // main term: 4 K-steps of 16 per 64-deep slab, 8 tiles = 4 A fragments x 2 B fragments
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t >> 1], b[t & 1], acc[t], 0, 0, 0);
+        if (MODE == 0) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(t >> 1) ^ p], b[(t & 1) ^ p], acc[t], 0, 0, 0);
+        } else if (MODE == 1 || MODE == 2) {
+            constexpr int FMT = MODE == 1 ? 0 : 2;      // 0 = fp8 e4m3, 2 = fp6 e2m3
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa[(t >> 1) ^ p], qb[(t & 1) ^ p], acc[t], FMT, FMT,
+                                                                           0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+        // keep the compiler from hoisting: perturb one operand register per slab
+        a[s & 3][0] += (_Float16)1e-3f;
+        qa[s & 3][0] ^= s;
+    }
+    float r = 0.f;
+    for (int t = 0; t < TILES; ++t)
+        for (int i = 0; i < 16; ++i) r += acc[t][i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+template <int MODE>
+static void run(const char* name, int waves, float* d_out) {
+    const int slabs = 4096, blocks = 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int r = 0; r < 4; ++r) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(mix_kernel<MODE>, dim3(blocks), dim3(64 * waves), 0, 0, d_out, slabs, 1.0f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (r) best = ms < best ? ms : best;
+    }
+    const double products = 2.0 * 32 * 32 * 64 * TILES * (double)slabs * waves * blocks;
+    printf("%-44s %2d waves/CU  %8.3f ms   %7.1f product TFLOP/s\n", name, waves, best, products / best / 1e9);
+}
+
+int main() {
+    float* d_out;
+    hipMalloc(&d_out, 256 * 512 * sizeof(float));
+    for (int waves = 4; waves <= 8; waves += 4) {
+        run<3>("D fp16 single pass (ceiling)", waves, d_out);
+        run<0>("A fp16 x 3 (shipped)", waves, d_out);
+        run<1>("B fp16 + 2 x fp8 K=64 cross terms", waves, d_out);
+        run<2>("C fp16 + 2 x fp6 K=64 cross terms", waves, d_out);
+    }
+    hipFree(d_out);
+    return 0;
+}
