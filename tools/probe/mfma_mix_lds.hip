@@ -1,0 +1,137 @@
+// mfma_mix.hip with the operand fragments READ FROM LDS every K step (read-only LDS, no global traffic, no barriers): does
+// the matrix-pipe gain of cheaper cross terms survive the LDS reads of a 128x64 wave tile (4 A x 2 B fragments = 8 accumulators,
+// the wide convolution kernel's wave)?  Per 64-deep K slab and wave:
+//   A  fp16 x 3:          96 x v_mfma_f32_32x32x16_f16, 48 x ds_read_b128   (hi and lo planes of 4 A + 2 B fragments, 4 K steps)
+//   C  fp16 + 2 x fp6:    32 x ..._f16 + 16 x v_mfma_scale_f32_32x32x64_f8f6f4, 24 x ds_read_b128 (fp16 hi) + 12 x (b128 + b64)
+//                         (packed fp6 hi and lo planes: 24 bytes per lane and fragment)
+//   B  fp16 + 2 x fp8:    like C with 12 x 2 x ds_read_b128 (32 bytes per lane and fragment)
+// Build + run:  hipcc --offload-arch=gfx950 -O2 tools/probe/mfma_mix_lds.hip -o /tmp/mixlds && /tmp/mixlds
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef int i8v __attribute__((ext_vector_type(8)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+
+constexpr int LDS_BYTES = 96 * 1024;
+
+template <int MODE>
+__global__ __launch_bounds__(512) void mix_kernel(float* out, int slabs) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    for (int i = threadIdx.x; i < LDS_BYTES / 4; i += blockDim.x) ((int*)lds)[i] = 0x38383838 + (i & 3);
+    __syncthreads();
+    f16v acc[8];
+    for (int t = 0; t < 8; ++t)
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // every fragment read: 64 lanes x 16 consecutive bytes (conflict-free), the fragment's base moves with wave / slab / step
+    const char* base = lds + lane * 16;
+    int off = wave * 4096;
+    for (int s = 0; s < slabs; ++s) {
+        off = (off + 8192) & (LDS_BYTES / 2 - 1);
+        const char* p = base + off;
+        if (MODE == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                h8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    ah[f] = *(const h8*)(p + (ks * 12 + f) * 1024);
+                    al[f] = *(const h8*)(p + (ks * 12 + 4 + f) * 1024);
+                }
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    bh[f] = *(const h8*)(p + (ks * 12 + 8 + f) * 1024);
+                    bl[f] = *(const h8*)(p + (ks * 12 + 10 + f) * 1024);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t >> 1], bh[t & 1], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t >> 1], bl[t & 1], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t >> 1], bh[t & 1], acc[t], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                h8 ah[4], bh[2];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) ah[f] = *(const h8*)(p + (ks * 6 + f) * 1024);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) bh[f] = *(const h8*)(p + (ks * 6 + 4 + f) * 1024);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t >> 1], bh[t & 1], acc[t], 0, 0, 0);
+            }
+            if (MODE == 1 || MODE == 2) {
+                constexpr int FMT = MODE == 1 ? 0 : 2;
+                i8v qa[2][4], qb[2][2];          // [hi | lo plane][fragment]
+                const char* q = p + 24 * 1024;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) {
+                        const char* r = q + (pl * 12 + f * 2) * 1024;
+                        const i4v lo4 = *(const i4v*)r;
+                        i8v v;
+                        v[0] = lo4[0]; v[1] = lo4[1]; v[2] = lo4[2]; v[3] = lo4[3];
+                        if (MODE == 1) {
+                            const i4v hi4 = *(const i4v*)(r + 1024);
+                            v[4] = hi4[0]; v[5] = hi4[1]; v[6] = hi4[2]; v[7] = hi4[3];
+                        } else {
+                            const i2v hi2 = *(const i2v*)(r + 1024 - lane * 8);      // 64 lanes x 8 bytes
+                            v[4] = hi2[0]; v[5] = hi2[1]; v[6] = 0; v[7] = 0;
+                        }
+                        if (f < 4) qa[pl][f] = v; else qb[pl][f - 4] = v;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa[0][t >> 1], qb[1][t & 1], acc[t], FMT, FMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa[1][t >> 1], qb[0][t & 1], acc[t], FMT, FMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            }
+        }
+    }
+    float r = 0.f;
+    for (int t = 0; t < 8; ++t)
+        for (int i = 0; i < 16; ++i) r += acc[t][i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+template <int MODE>
+static void run(const char* name, int waves, float* d_out) {
+    const int slabs = 2048, blocks = 256;
+    hipFuncSetAttribute((const void*)mix_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int r = 0; r < 4; ++r) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(mix_kernel<MODE>, dim3(blocks), dim3(64 * waves), LDS_BYTES, 0, d_out, slabs);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (r) best = ms < best ? ms : best;
+    }
+    const double products = 2.0 * 32 * 32 * 64 * 8 * (double)slabs * waves * blocks;
+    printf("%-52s %2d waves/CU  %8.3f ms   %7.1f product TFLOP/s  (%s)\n", name, waves, best, products / best / 1e9,
+           hipGetErrorString(hipGetLastError()));
+}
+
+int main() {
+    float* d_out;
+    hipMalloc(&d_out, 256 * 512 * sizeof(float));
+    for (int waves = 4; waves <= 8; waves += 4) {
+        run<3>("D fp16 single pass, fragments from LDS", waves, d_out);
+        run<0>("A fp16 x 3 (shipped), fragments from LDS", waves, d_out);
+        run<1>("B fp16 + 2 x fp8 cross terms, fragments from LDS", waves, d_out);
+        run<2>("C fp16 + 2 x fp6 cross terms, fragments from LDS", waves, d_out);
+    }
+    hipFree(d_out);
+    return 0;
+}
