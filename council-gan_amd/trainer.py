@@ -818,12 +818,6 @@ class Council_Trainer(nn.Module):
                             x_full[d][lead] = gen.decode(content, s_dev[(d, g)], xr)
                             ops.take_rows(x_full[d][lead], None, list(range(g * b)), out=x_cmp_local[d][k0 * b:(k0 + g) * b])
         self._join()      # every member's council discriminator reads the OTHER members' images
-        if os.environ.get('CG_DIAG_DBG'):
-            d0 = self._dirs[0]
-            return {'_x_full': x_full, '_x_cmp_local': x_cmp_local,
-                    '_dbg1': {'x_full': x_full[d0][groups[0][0]], 'x_cmp_local': x_cmp_local[d0], 'x': x[d0],
-                              'content': self._content(d0, groups[0], self._rep(x[d0], len(groups[0])), need_grad=False),
-                              's': s_dev[(d0, len(groups[0]))], 'rep2': self._rep(x[d0], 2 * len(groups[0]))}}
         return {'_x_full': x_full, '_x_cmp_local': x_cmp_local}
 
     def _disc_body_update(self, x, x_cmp, groups, plans, scale, hyper):
@@ -958,9 +952,6 @@ class Council_Trainer(nn.Module):
                         content_in = self._content(d, grp, xr, need_grad=True)
                         x_fake = gen.decode(content_in, s_dev[(d, g)], xr)
                         mask = gen.dec.mask_s
-                        if os.environ.get('CG_DIAG_DBG'):
-                            out.setdefault('_dbg', {}).update({d + '/content': content_in.detach(), d + '/x_fake': x_fake.detach(),
-                                                               d + '/mask': mask.detach(), d + '/s': s_dev[(d, g)], d + '/xr': xr})
                         ftot = adv = lc = w_dev = None
                         if f['focus_on']:                                                   # :390-451
                             ftot, parts = ops.focus_loss(mask, f['center'], f['eps'], f['zo_w'], f['total_w'], f['tv_w'],

@@ -58,11 +58,6 @@ def _run(cga, cfg, graph, iters, size, group_max=None, overlap=None):
         tr.gen_update(x_a, x_b, c, c['iteration'])
         torch.cuda.synchronize()
         row = {n: [float(v) for v in getattr(tr, n, [])] for n in names}
-        if os.environ.get('CG_DIAG_DBG'):
-            for k, v in getattr(tr, '_dbg', {}).items():
-                row['dbg.' + k] = [float(v.double().abs().sum())]
-            for k, v in getattr(tr, '_dbg1', {}).items():
-                row['dbg1.' + k] = [float(v.double().abs().sum())]
         if os.environ.get('CG_DIAG_POOLS'):      # per-pool checksums of weights / gradients / moments (tools/diag_graph.py)
             for kind, pool in tr._pools.items():
                 for nm in ('data', 'grad', 'm', 'v'):
