@@ -53,6 +53,7 @@ import yaml  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 F16X3_PEAK_TFLOPS = 2500.0 / 3    # split-precision kernels: dense fp16 MFMA peak / 3 MFMA passes per product
+MFMA_MIX_CEILING_TFLOPS = 702.4   # registers-only probe of the fp16 x 3 product on one MI355X (profiles/r03_mfma_mix.txt)
 
 
 def pmc_traffic(kernel):
@@ -399,6 +400,12 @@ def main():
                          "all_conv_kernels_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                          "conv_ms_per_step": round(tot_ms, 2), "executed_conv_tflop_per_step": round(tot_fl / 1e12, 3),
                          "kernels": kernels})
+            if kernel_peak(dname) == F16X3_PEAK_TFLOPS:
+                # what the matrix pipe sustains on this very instruction mix with NO memory traffic at all (3 dependent-free
+                # v_mfma_f32_32x32x16_f16 per product, 8 accumulators per wave, one block per CU, power-limited clock):
+                # committed measurement, tools/probe/mfma_mix.hip -> profiles/r03_mfma_mix.txt
+                roof["pipe_ceiling"] = {"value": MFMA_MIX_CEILING_TFLOPS, "unit": "TFLOP/s (a.b products)",
+                                        "frac": round(ach / MFMA_MIX_CEILING_TFLOPS, 4), "source": "profiles/r03_mfma_mix.txt"}
         else:
             roof.update({"achieved": round(step_tflops, 2), "frac": round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4)})
         out["roofline"] = roof
