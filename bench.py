@@ -459,7 +459,7 @@ def main():
                 out["n1_same_config"] = {"value": one["value"], "ms_per_step": one["ms_per_step"], "source": os.path.relpath(rec, ROOT),
                                          "speedup": round(value / one["value"], 3),
                                          "note": "committed single-GPU record of this configuration, a different box and day"}
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError):      # no usable record: the line goes without it
             pass
         out["collective_backend"] = dist.get_backend() + (" (native C-ABI communicators)" if trainer.shard.slice_comm is not None else "")
         out["rccl_version"] = rccl_version() if dist.get_backend() == "nccl" else None
