@@ -196,6 +196,35 @@ def test_flat_adam_views_and_state_dict_on_host():
         assert torch.allclose(back["state"][i]["exp_avg"], ref.state_dict()["state"][i]["exp_avg"])
 
 
+def test_adam_step_scalars_on_host():
+    """cg_adam_hyper (host arithmetic, no kernel): the two per-step scalars hipGraph mode stages into device memory are
+    torch.optim.Adam's step_size and sqrt(bias_correction2) (trainer_council.py:170-179 builds torch.optim.Adam), rounded
+    once from double; ParamPool.plan_hyper / advance keep the host-side step counts a replayed step would."""
+    lib = cga.hip.load()
+    buf = (ctypes.c_float * 2)()
+    for lr, b1, b2, step in ((1e-4, 0.5, 0.999, 1), (1e-4, 0.5, 0.999, 2), (5e-5, 0.5, 0.999, 1000), (1e-3, 0.9, 0.99, 37)):
+        assert lib.cg_adam_hyper(lr, b1, b2, step, buf) == 0
+        assert buf[0] == np.float32(np.float64(np.float32(lr)) / (1.0 - np.float64(np.float32(b1)) ** step))
+        assert buf[1] == np.float32(np.sqrt(1.0 - np.float64(np.float32(b2)) ** step))
+    assert lib.cg_adam_hyper(1e-4, 0.5, 0.999, 0, buf) != 0 and b"cg_adam_hyper" in lib.cg_last_error()
+
+    nets = [torch.nn.Conv2d(4, 8, 3) for _ in range(2)]
+    opts = [cga.FlatAdam(list(n.parameters()), lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-4) for n in nets]
+    pool = cga.optim.ParamPool(opts)
+    pool.materialize('cpu')
+    assert pool.plan_hyper(0, 2) is None                  # the runs of a step are unknown before its first execution
+    runs = [(0, 2)]
+    pool._runs = {(0, 2): runs}
+    v0 = pool.version
+    h1 = pool.plan_hyper(0, 2)
+    assert tuple(h1.shape) == (1, 2) and float(h1[0, 0]) == np.float32(1e-4 / 0.5)
+    pool.advance(0, 2, runs)
+    assert [o._steps for o in opts] == [[1, 1], [1, 1]] and pool.version == v0 + 2
+    h2 = pool.plan_hyper(0, 2)
+    assert float(h2[0, 0]) == np.float32(np.float64(np.float32(1e-4)) / (1.0 - 0.25))
+    assert float(h2[0, 1]) == np.float32(np.sqrt(1.0 - np.float64(np.float32(0.999)) ** 2))
+
+
 def test_schedules_match_oracle():
     g = Golden("m2f_c3")
     for it in (0, 9999, 10000, 10001, 60000):
