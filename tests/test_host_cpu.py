@@ -225,6 +225,52 @@ def test_adam_step_scalars_on_host():
     assert float(h2[0, 1]) == np.float32(np.sqrt(1.0 - np.float64(np.float32(0.999)) ** 2))
 
 
+def test_council_discriminator_batch_plan():
+    """MsImageDisCouncil.plan_members (host half of the member-batched council-discriminator objective) against the
+    reference's loop (trainer_council.py:861-874): for every pick k of member m -- repeats included -- one
+    mean(D(own)^2) + mean((D(colleague_k) - 1)^2) term, all scaled by council_w / n_rel."""
+    b, scale = 2, 0.25
+    draws = [[1, 3, 1], [0, 2, 2]]                          # member 0 drew colleague 1 twice, member 1 colleague 2 twice
+    pk = [[(j, float(d.count(j))) for j in sorted(set(d))] for d in draws]
+    idx, idx_in, tgt, wt = cga.networks.MsImageDisCouncil.plan_members(pk, 2, b, float(len(draws[0])), scale)
+    rows = 2 * (1 + 2) * b                                  # per member: own + two distinct colleagues, b samples each
+    assert len(idx) == len(tgt) == len(wt) == len(idx_in) == rows
+    for m, d in enumerate(draws):
+        base = m * 3 * b
+        # own translations: rows m*b .. of x_full (non-negative indices), target 0, weight = one fake term per pick
+        assert idx[base:base + b] == [m * b + r for r in range(b)]
+        assert tgt[base:base + b] == [0.0] * b and wt[base:base + b] == [scale * len(d)] * b
+        for u, j in enumerate(sorted(set(d))):
+            lo = base + (1 + u) * b
+            # colleague j: rows of x_cmp as negative indices -(row) - 1 (ops.take_rows), target 1, weight = its multiplicity
+            assert idx[lo:lo + b] == [-(j * b + r) - 1 for r in range(b)]
+            assert tgt[lo:lo + b] == [1.0] * b and wt[lo:lo + b] == [scale * d.count(j)] * b
+        assert idx_in[base:base + 3 * b] == list(range(b)) * 3       # every block is conditioned on the same input batch
+    with pytest.raises(ValueError):
+        cga.networks.MsImageDisCouncil.plan_members([pk[0], pk[1][:1]], 2, b, 3.0, scale)
+
+
+def test_member_groups_respect_the_31_bit_offsets():
+    """Council_Trainer._plan_groups: as many members per launch as divide the local members, fit CG_GROUP and keep the
+    largest batched activation (the council discriminator's first full-resolution map) below 2 GiB."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "male2female_council_folder.yaml")))
+
+    def groups(council, batch, size):
+        c = copy.deepcopy(cfg)
+        c['council']['council_size'] = council
+        tr = cga.Council_Trainer(c, 'cuda:0')                 # host-side construction only
+        tr._group_max, tr._groups, tr._hp_last = 4, None, c
+        return tr._plan_groups(torch.empty((batch, 3, size, size), device='meta'))
+    assert groups(4, 4, 256) == [[0, 1, 2, 3]]                 # 4 x 336 MB
+    assert groups(8, 4, 256) == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    assert groups(4, 8, 256) == [[0, 1], [2, 3]]               # 4 x 671 MB would cross 2 GiB
+    assert groups(2, 16, 256) == [[0, 1]]                      # council 2: one colleague -> 2 x 16 samples per member, 2 x 0.5 GiB
+    assert groups(2, 32, 256) == [[0], [1]]                    # 2 x 1 GiB would not fit
+    with pytest.raises(cga.hip.HipError):
+        groups(2, 64, 256)                                     # one member alone: 2 GiB
+
+
 def test_schedules_match_oracle():
     g = Golden("m2f_c3")
     for it in (0, 9999, 10000, 10001, 60000):
