@@ -271,6 +271,35 @@ def test_member_groups_respect_the_31_bit_offsets():
         groups(2, 64, 256)                                     # one member alone: 2 GiB
 
 
+def test_bench_work_model_and_traffic_record():
+    """bench.py's roofline inputs: W_min per iteration is SURVEY.md section 8d's table (0.130 / 1.040 / 14.68 / 31.0 TFLOP for
+    configurations 1 / 2 / 3 / 5), the split-precision peak is the fp16 dense peak over three passes, and the committed PMC
+    record the `traffic` field comes from names the dominant kernel, its bytes per launch and the build it was taken on."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert abs(bench.w_min_tflop(1, 128, 1, 4) - 0.130) < 5e-4
+    assert abs(bench.w_min_tflop(8, 128, 1, 4) - 1.040) < 5e-4
+    assert abs(bench.w_min_tflop(4, 256, 4, 4) - 14.68) < 5e-3
+    assert abs(bench.w_min_tflop(4, 256, 8, 4) - 31.0) < 5e-2
+    assert abs(bench.F16X3_PEAK_TFLOPS - 2500.0 / 3) < 1e-9 and bench.FP32_MFMA_PEAK_TFLOPS == 157.3
+    assert bench.kernel_peak("conv_fwd_x3w_kernel<256,256,fast>") == bench.F16X3_PEAK_TFLOPS
+    assert bench.kernel_peak("conv_fwd_thin_kernel<256,64,fast>") == bench.FP32_MFMA_PEAK_TFLOPS
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    name = "conv_fwd_x3w_kernel<256,256,fast>"
+    assert name in rec
+    nbytes, r = bench.pmc_traffic(name)
+    # gfx950: FETCH_SIZE counts a 128-byte request as 64 bytes -> x 2 (MI355X_MICROARCH.md); WRITE_SIZE as is; both in KiB
+    assert nbytes == rec[name]["bytes_per_launch"] == 1024 * (2 * rec[name]["fetch_size_kib"] + rec[name]["write_size_kib"])
+    assert nbytes > rec[name]["algorithmic_bytes_per_launch"] > 0 and len(rec[name]["build_stamp"]) == 16
+    assert set(("same_build", "build_stamp_now")) <= set(r)
+    assert bench.pmc_traffic("no_such_kernel") == (None, None)
+    for cfg_id, p in bench.PRESETS.items():
+        assert os.path.exists(os.path.join(ROOT, "configs", p["config"])), cfg_id
+
+
 def test_schedules_match_oracle():
     g = Golden("m2f_c3")
     for it in (0, 9999, 10000, 10001, 60000):
