@@ -531,6 +531,7 @@ class Council_Trainer(nn.Module):
                     gc.collect()
                     gc_was_on = gc.isenabled()
                     gc.disable()
+                    failed = None
                     try:
                         # capture_error_mode "thread_local": only the capturing thread is policed.  Under "global" (torch's
                         # default) a potentially-unsafe HIP call from ANY thread invalidates the capture -- and the
@@ -538,11 +539,23 @@ class Council_Trainer(nn.Module):
                         with torch.cuda.graph(g, stream=cap, capture_error_mode=os.environ.get('CG_GRAPH_CAPTURE_MODE', 'thread_local')):
                             seg.out = body()
                         seg.effects = self._recording
+                    except Exception as e:      # noqa: BLE001 -- whatever stopped the capture, the eager path below still stands
+                        failed = e
                     finally:
                         self._recording = None
                         if gc_was_on:
                             gc.enable()
                     cur.wait_stream(cap)
+                    if failed is not None:
+                        # A capture launches nothing and applies no host-side effect (they were being recorded), so the update
+                        # has not happened yet: leave graph mode for good and run it -- and everything after it -- eagerly.
+                        # Same kernels, same numbers; a genuine error of the body shows up again, from the eager run.
+                        torch.cuda.set_stream(cur)       # (a capture that died in its begin / end leaves the capture stream current)
+                        self._leave_graph_mode(key, failed)
+                        out = body()
+                        for k, v in out.items():
+                            setattr(self, k, v)
+                        return
                     seg.graph, seg.generation = g, self._hin.generation
                 seg.graph.replay()
                 for fn in seg.effects:
@@ -550,6 +563,22 @@ class Council_Trainer(nn.Module):
                 out = seg.out
         for k, v in out.items():
             setattr(self, k, v)
+
+    def _leave_graph_mode(self, key, err):
+        """A segment could not be captured (a driver / collective-library interaction this build has not met): drop every
+        reference to tensors of the abandoned capture and continue eagerly for the rest of the run."""
+        warnings.warn("council-gan_amd: hipGraph capture of segment %r failed (%s: %s); continuing WITHOUT graph replay "
+                      "(CG_GRAPH=0 selects that from the start)" % (key[0], type(err).__name__, err))
+        self._graph_mode = False
+        self._iter_eager = True
+        seg = self._segs.get(key)
+        if seg is not None:
+            seg.graph, seg.out, seg.effects = None, None, []
+        self._rep_cache.clear()
+        self._enc_cache.clear()
+        for pool in self._pools.values():
+            if pool.split is not None:
+                pool.split._dgrad = {}
 
     def _static(self, name, t):
         """Graph mode, several ranks: the result of an eager collective is copied into a static buffer (captured kernels

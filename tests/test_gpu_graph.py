@@ -35,7 +35,7 @@ def _tiny(name, council, batch):
     return cfg
 
 
-def _run(cga, cfg, graph, iters, size, group_max=None, overlap=None):
+def _run(cga, cfg, graph, iters, size, group_max=None, overlap=None, expect_graph_mode_after=None):
     c = copy.deepcopy(cfg)
     c['cg_graph'] = '1' if graph else '0'
     O.seed_all(11)
@@ -76,6 +76,8 @@ def _run(cga, cfg, graph, iters, size, group_max=None, overlap=None):
     steps = [list(o._steps) for o in tr.gen_opt_s]
     ring = {d: list(tr._ring_pos[d]) for d in tr._dirs}
     captured = sum(1 for s in tr._segs.values() if s.graph is not None)
+    if expect_graph_mode_after is not None:
+        assert tr._graph_mode == expect_graph_mode_after
     del tr
     return rows, w, steps, ring, captured
 
@@ -98,6 +100,34 @@ def test_graph_replay_is_bit_identical_to_eager(cga, case):
         cga.ops.X3_FORWARD = cga.ops.X3_BACKWARD = cga.ops.X3_DYNAMIC_INPUT = True
     assert e_cap == 0 and g_cap >= 4, (e_cap, g_cap)          # dis, disc1, disc2, gen
     assert e_rows == g_rows, [(a, b) for a, b in zip(e_rows, g_rows) if a != b][:2]
+    assert e_steps == g_steps and e_ring == g_ring
+    for k in e_w:
+        assert torch.equal(e_w[k], g_w[k]), k
+
+
+@pytest.mark.parametrize("fail_at", [1, 2, 4])
+def test_a_failed_capture_falls_back_to_eager(cga, fail_at, monkeypatch):
+    """If a segment cannot be captured (here: torch.cuda.graph made to fail on its fail_at-th use -- the first segment, one in
+    the middle of an iteration, the last one), the trainer warns, leaves graph mode and runs that update and everything
+    after it eagerly: the numbers are those of the eager run, nothing is applied twice or skipped."""
+    cfg = _tiny("male2female_council_folder.yaml", 2, 2)
+    real, uses = torch.cuda.graph, [0]
+
+    class Flaky(real):
+        def __enter__(self):
+            uses[0] += 1
+            if uses[0] == fail_at:
+                raise RuntimeError("injected: operation not permitted when stream is capturing")
+            return super().__enter__()
+    try:
+        e_rows, e_w, e_steps, e_ring, _ = _run(cga, cfg, False, 4, 64)
+        monkeypatch.setattr(torch.cuda, "graph", Flaky)
+        with pytest.warns(UserWarning, match="hipGraph capture of segment"):
+            g_rows, g_w, g_steps, g_ring, _ = _run(cga, cfg, True, 4, 64, expect_graph_mode_after=False)
+    finally:
+        cga.ops.X3_FORWARD = cga.ops.X3_BACKWARD = cga.ops.X3_DYNAMIC_INPUT = True
+    assert uses[0] == fail_at
+    assert e_rows == g_rows
     assert e_steps == g_steps and e_ring == g_ring
     for k in e_w:
         assert torch.equal(e_w[k], g_w[k]), k
