@@ -16,6 +16,7 @@
 //   optional two-source channel concat); Wp is [Cout][T][Ct], k-contiguous.
 // GEMM view (wgrad):  dW[j][k] = sum_m dz[m][j] * A[m][k]   (split over m, deterministic reduce)
 #include <stddef.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -2685,6 +2686,239 @@ extern "C" int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, s
     if (rc) return rc;
     return cg_conv2d_dgrad_x3_run(g, nullptr, dz_split, dz_lo_elems, dz_scale_dev, ws, CG_X3_WSCALE, nullptr, ci0, nci, dx, nullptr,
                                   nullptr, stream);
+}
+
+// ---- nearest-2x upsample + 3x3 convolution = a 4x4 stride-2 TRANSPOSED convolution ---------------------------------
+// nn.Upsample(scale_factor=2) -> ZeroPad2d(1) -> Conv2d(3x3) (networks.py:385-386, Conv2dBlock :513-516).  The upsampled image
+// repeats every source pixel 2x2, so the 3x3 taps that land on the SAME source pixel can be added up first: output row
+// Y = 2i - 1 + u (u = 0..3) receives source row i through the summed kernel rows  S(0) = {2}, S(1) = {1,2}, S(2) = {0,1},
+// S(3) = {0}  (likewise for columns) -- 16 effective taps for 4 output pixels instead of 36: 2.25x fewer multiply-adds,
+// forward and backward.  With W_F[u][v] = sum_{kh in S(u), kw in S(v)} W[kh][kw]:
+//   forward        y  = conv_transpose(x, W_F, stride 2, pad 1) = the four output-parity classes (2x2 taps each) of the
+//                       data-gradient machinery above, with bias and instance-norm partials        (cg_upconv2d_fwd_x3)
+//   data gradient  dx = conv(dz, W_F as [Cin][4][4][Cout], stride 2, pad 1)                         (cg_conv2d_fwd_x3_g)
+//   weight grad    dW_F[ci][u][v][co] = wgrad of that 4x4 stride-2 conv (input dz, output gradient x)  (cg_conv2d_wgrad_x3_g),
+//                  folded back onto the nine taps: dW[co][kh][kw][ci] += sum_{u: kh in S(u), v: kw in S(v)} dW_F[ci][u][v][co]
+// The sums are formed in fp32 from the fp32 weights and then split: same 22-bit products as every other convolution here.
+namespace {
+__host__ __device__ inline int upc_first(int u) { return u == 0 ? 2 : (u == 1 ? 1 : 0); }      // S(u) = {first, .., first + n - 1}
+__host__ __device__ inline int upc_count(int u) { return (u == 1 || u == 2) ? 2 : 1; }
+
+// mode 0: forward classes.  class (p, q), tap (a, b) <-> u = p + 1 - 2*dy with dy = a - 1 (p == 0) / a (p == 1):
+//         out[cls * Cout*4*Cin + (co*4 + a*2+b) * Cin + ci];   mode 1: backward, out[(ci*16 + u*4+v) * Cout + co]
+__global__ __launch_bounds__(256) void upconv_prep_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Cout,
+                                                          int Cin, float scale, const float* __restrict__ scale_dev,
+                                                          unsigned lo_elems, long long w_mstride, int mode) {
+    const size_t per = (size_t)16 * Cout * Cin;
+    const int member = blockIdx.y;
+    w += (long long)member * w_mstride;
+    out += (size_t)member * per * 2;          // 4 bytes per element in the interleaved {hi, lo} form
+    if (scale_dev) scale *= scale_dev[0];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+        int co, ci, u, v;
+        size_t o;
+        if (mode == 0) {      // i = ((cls*Cout + co)*4 + tap)*Cin + ci
+            ci = (int)(i % Cin);
+            size_t r = i / Cin;
+            const int tap = (int)(r & 3);
+            r >>= 2;
+            co = (int)(r % Cout);
+            const int cls = (int)(r / Cout);
+            const int p = cls >> 1, q = cls & 1, a = tap >> 1, b = tap & 1;
+            u = p + 1 - 2 * (p ? a : a - 1);
+            v = q + 1 - 2 * (q ? b : b - 1);
+            o = i;
+        } else {              // i = (ci*16 + uv)*Cout + co
+            co = (int)(i % Cout);
+            size_t r = i / Cout;
+            const int uv = (int)(r & 15);
+            ci = (int)(r >> 4);
+            u = uv >> 2;
+            v = uv & 3;
+            o = i;
+        }
+        float acc = 0.f;
+        for (int kh = upc_first(u); kh < upc_first(u) + upc_count(u); ++kh)
+            for (int kw = upc_first(v); kw < upc_first(v) + upc_count(v); ++kw) acc += w[((size_t)co * 9 + kh * 3 + kw) * Cin + ci];
+        _Float16 h, l;
+        split_f16(acc * scale, h, l);
+        out[cg_il(o)] = h;
+        out[lo_elems + cg_il(o)] = l;
+    }
+}
+
+// dw[co][kh][kw][ci] (+)= sum over the (u, v) whose S(u) x S(v) contains (kh, kw) of dwf[ci][u][v][co]
+__global__ __launch_bounds__(256) void upconv_fold_kernel(const float* __restrict__ dwf, float* __restrict__ dw, int Cout, int Cin,
+                                                          long long dw_mstride, int accumulate) {
+    __shared__ float tile[32][33];
+    const int member = blockIdx.z / 9, t = blockIdx.z % 9, kh = t / 3, kw = t % 3;
+    dwf += (size_t)member * 16 * Cout * Cin;
+    dw += (long long)member * dw_mstride;
+    const int cib = blockIdx.x * 32, cob = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {        // tile[ci][co], co fastest in dwf
+        const int ci = cib + r, co = cob + tx;
+        float a = 0.f;
+        if (ci < Cin && co < Cout)
+            for (int u = 0; u < 4; ++u) {
+                if (kh < upc_first(u) || kh >= upc_first(u) + upc_count(u)) continue;
+                for (int v = 0; v < 4; ++v) {
+                    if (kw < upc_first(v) || kw >= upc_first(v) + upc_count(v)) continue;
+                    a += dwf[((size_t)ci * 16 + u * 4 + v) * Cout + co];
+                }
+            }
+        tile[r][tx] = a;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {        // ci fastest in dw
+        const int co = cob + r, ci = cib + tx;
+        if (co < Cout && ci < Cin) {
+            float* o = dw + ((size_t)co * 9 + t) * Cin + ci;
+            *o = accumulate ? *o + tile[tx][r] : tile[tx][r];
+        }
+    }
+}
+
+// column sums of a {hi, lo} tensor [rows][C] (the bias gradient of a layer whose dz exists in split form only): one block per
+// (member, row chunk) writes C partial sums, a second launch adds the chunks in a fixed order
+__global__ __launch_bounds__(256) void colsum_split_kernel(const _Float16* __restrict__ zs, unsigned lo_elems, int rows, int C,
+                                                           int chunks, float* __restrict__ part) {
+    const int member = blockIdx.y, chunk = blockIdx.x;
+    const int per = (rows + chunks - 1) / chunks;
+    const int r0 = chunk * per, r1 = min(rows, r0 + per);
+    const int c = threadIdx.x % C, rr = threadIdx.x / C, rstep = 256 / C;      // C <= 256, 256 % C == 0
+    float a = 0.f;
+    for (int r = r0 + rr; r < r1; r += rstep) {
+        const size_t e = ((size_t)member * rows + r) * C + c;
+        a += (float)zs[cg_il(e)] + (float)zs[lo_elems + cg_il(e)];
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        for (int k = 1; k < rstep; ++k) a += red[threadIdx.x + k * C];
+        part[((size_t)member * chunks + chunk) * C + threadIdx.x] = a;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int C, int chunks,
+                                                           const float* __restrict__ scale_dev, float* __restrict__ db,
+                                                           long long db_mstride, int accumulate) {
+    const int member = blockIdx.x, c = threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int k = 0; k < chunks; ++k) a += part[((size_t)member * chunks + k) * C + c];
+    if (scale_dev) a *= 1.f / scale_dev[0];
+    float* o = db + (long long)member * db_mstride + c;
+    *o = accumulate ? *o + a : a;
+}
+}  // namespace
+
+extern "C" size_t cg_upconv_wt_elems(int Cout, int Cin) { return (size_t)16 * Cout * Cin; }
+
+extern "C" int cg_upconv_prep_x3(const cg_group* group, const float* w, int Cout, int Cin, float w_scale,
+                                 const float* w_scale_dev, void* wt_fwd, void* wt_bwd, cg_stream_t stream) {
+    CG_CHECK_ARG(w && (wt_fwd || wt_bwd) && Cout > 0 && Cin > 0 && Cout % 32 == 0 && Cin % 32 == 0 && w_scale > 0.f,
+                 "cg_upconv_prep_x3: bad args (channel counts must be multiples of 32)");
+    CG_CHECK_ARG(CG_X3_INTERLEAVE, "cg_upconv_prep_x3: needs the interleaved operand layout");
+    const int n = group ? group->n : 1;
+    const long long ms = group ? group->stride : 0;
+    CG_CHECK_ARG(n >= 1, "cg_upconv_prep_x3: bad group");
+    const size_t per = cg_upconv_wt_elems(Cout, Cin);
+    dim3 grid((unsigned)std::min<size_t>((per + 255) / 256, 1024), n);
+    if (wt_fwd)
+        hipLaunchKernelGGL(upconv_prep_kernel, grid, dim3(256), 0, cg_s(stream), w, (_Float16*)wt_fwd, Cout, Cin, w_scale,
+                           w_scale_dev, (unsigned)CG_X3_LO_ELEMS, ms, 0);
+    if (wt_bwd)
+        hipLaunchKernelGGL(upconv_prep_kernel, grid, dim3(256), 0, cg_s(stream), w, (_Float16*)wt_bwd, Cout, Cin, w_scale,
+                           w_scale_dev, (unsigned)CG_X3_LO_ELEMS, ms, 1);
+    CG_LAUNCH_CHECK("upconv_prep_kernel");
+    return CG_OK;
+}
+
+extern "C" int cg_upconv2d_fwd_x3(const cg_conv_geom* g, const cg_group* group, const void* xs, size_t x_lo_elems,
+                                  const float* x_scale_dev, const void* wt_fwd, float w_scale, const float* w_scale_dev,
+                                  const float* bias, float* y, double* stats, size_t stats_bytes, int* rows_per_partial,
+                                  cg_stream_t stream) {
+    const char* who = "cg_upconv2d_fwd_x3";
+    int rc = validate_geom(g, who);
+    if (rc) return rc;
+    if (rows_per_partial) *rows_per_partial = 0;
+    CG_CHECK_ARG(xs && wt_fwd && y && w_scale > 0.f, "%s: null pointer / bad scale", who);
+    CG_CHECK_ARG(CG_X3_INTERLEAVE && g->up == 1 && g->T == 9 && g->stride == 1 && g->C2 == 0 && g->C1 % 32 == 0 && g->Cout % 32 == 0 &&
+                     g->Ho == 2 * g->H && g->Wo == 2 * g->W && g->osy == 1 && g->osx == 1,
+                 "%s: needs a 3x3 stride-1 pad-1 convolution on a 2x upsampled source, channels multiples of 32", who);
+    for (int t = 0; t < 9; ++t)
+        CG_CHECK_ARG(g->dy[t] == t / 3 - 1 && g->dx[t] == t % 3 - 1, "%s: taps must be the 3x3 pad-1 window", who);
+    Grp gr;
+    rc = grp_from(group, g->N, gr, who);
+    if (rc) return rc;
+    const size_t x_plane = (size_t)g->N * g->H * g->W * g->C1 * 2;
+    CG_CHECK_ARG(x3_lo_ok(x_lo_elems, x_plane) && x3_span(x_lo_elems, x_plane) < (size_t)CG_OOB, "%s: operand planes out of range", who);
+    const size_t cls_elems = (size_t)g->Cout * 4 * g->C1, wt_elems = 4 * cls_elems;
+    CG_CHECK_ARG(4 * wt_elems < (size_t)CG_OOB, "%s: weight tensor too large", who);
+    PipeBatch b;
+    long m_total = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int p = c >> 1, q = c & 1;
+        cg_conv_geom cg;
+        memset(&cg, 0, sizeof(cg));
+        cg.N = g->N; cg.H = g->H; cg.W = g->W; cg.C1 = g->C1; cg.C2 = 0; cg.up = 0;
+        cg.Ho = g->H; cg.Wo = g->W; cg.HoF = g->Ho; cg.WoF = g->Wo;
+        cg.osy = cg.osx = 2; cg.ooy = p; cg.oox = q;
+        cg.stride = 1; cg.T = 4; cg.Cout = g->Cout; cg.act = g->act;
+        for (int a = 0; a < 2; ++a)
+            for (int bb = 0; bb < 2; ++bb) {
+                cg.dy[a * 2 + bb] = (int8_t)(p ? a : a - 1);
+                cg.dx[a * 2 + bb] = (int8_t)(q ? bb : bb - 1);
+            }
+        fill_class(b.c[c], &cg, (const float*)((const _Float16*)wt_fwd + cg_il(c * cls_elems)), gr.n);
+        b.c[c].w_bytes = (unsigned)(CG_X3_LO_ELEMS * 2);
+        b.c[c].pad_ = (int32_t)(4 * wt_elems - 2 * cg_il(c * cls_elems));
+        m_total += (long)b.c[c].M * gr.n;
+    }
+    const int cfg = pick_x3_cfg(g->Cout, m_total, g->C1, 4);
+    const int bm = x3_cfg_bm(cfg);
+    double* st_ptr = nullptr;
+    if (rows_per_partial && stats && g->act == CG_ACT_NONE && (g->H * g->W) % bm == 0 &&
+        stats_bytes >= (size_t)(m_total / bm) * g->Cout * 2 * sizeof(double)) {
+        st_ptr = stats;              // partial T = (row tile) * 4 + class: the tiles of a sample stay consecutive
+        *rows_per_partial = bm;
+    }
+    X3Extra ex;
+    ex.w_scale_dev = w_scale_dev;
+    ex.mb = Members{gr.n, 0, (long long)wt_elems * 4, gr.stride * 4};
+    fwd_amax.state = nullptr;
+    return launch_x3_cfg(cfg, b, 4, xs, bias, y, (unsigned)(x_lo_elems * 2), (unsigned)x3_span(x_lo_elems, x_plane), 1.0f / w_scale,
+                         x_scale_dev, cg_s(stream), st_ptr, nullptr, 0, ex);
+}
+
+extern "C" int cg_upconv_fold_dw(const cg_group* group, const float* dwf, float* dw, int Cout, int Cin, int accumulate,
+                                 cg_stream_t stream) {
+    CG_CHECK_ARG(dwf && dw && Cout > 0 && Cin > 0, "cg_upconv_fold_dw: bad args");
+    const int n = group ? group->n : 1;
+    const long long ms = group ? group->stride : 0;
+    hipLaunchKernelGGL(upconv_fold_kernel, dim3(cg_div_up(Cin, 32), cg_div_up(Cout, 32), 9 * n), dim3(256), 0, cg_s(stream), dwf, dw,
+                       Cout, Cin, ms, accumulate);
+    CG_LAUNCH_CHECK("upconv_fold_kernel");
+    return CG_OK;
+}
+
+extern "C" size_t cg_colsum_split_workspace(int C, int nmember) { return (size_t)nmember * 256 * C * sizeof(float); }
+
+extern "C" int cg_colsum_split(const cg_group* group, const void* zs, size_t lo_elems, const float* scale_dev, long rows_total,
+                               int C, float* db, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
+    const int n = group ? group->n : 1;
+    const long long ms = group ? group->stride : 0;
+    CG_CHECK_ARG(zs && db && ws && C > 0 && C <= 256 && 256 % C == 0 && rows_total > 0 && rows_total % n == 0 &&
+                     x3_lo_ok(lo_elems, (size_t)rows_total * C * 2),
+                 "cg_colsum_split: bad args (C must divide 256)");
+    if (ws_bytes < cg_colsum_split_workspace(C, n)) return cg_set_error(CG_ERR_WORKSPACE, "cg_colsum_split: workspace too small");
+    const int rows = (int)(rows_total / n), chunks = 256;
+    hipLaunchKernelGGL(colsum_split_kernel, dim3(chunks, n), dim3(256), 0, cg_s(stream), (const _Float16*)zs, (unsigned)lo_elems, rows,
+                       C, chunks, (float*)ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(n), dim3(256), 0, cg_s(stream), (const float*)ws, C, chunks, scale_dev, db, ms,
+                       accumulate);
+    CG_LAUNCH_CHECK("colsum_split_kernel");
+    return CG_OK;
 }
 
 extern "C" int cg_x3_interleaved(void) { return CG_X3_INTERLEAVE; }

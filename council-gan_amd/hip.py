@@ -63,6 +63,13 @@ _SIGS = {
     "cg_conv2d_dgrad_x3_prep": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
     "cg_conv2d_dgrad_x3_run": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_float, _P, c_int, c_int, _P, _P,
                                        POINTER(c_int), _P]),
+    "cg_upconv_wt_elems": (c_size_t, [c_int, c_int]),
+    "cg_upconv_prep_x3": (c_int, [POINTER(Group), _P, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "cg_upconv2d_fwd_x3": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_float, _P, _P, _P, _P, c_size_t,
+                                   POINTER(c_int), _P]),
+    "cg_upconv_fold_dw": (c_int, [POINTER(Group), _P, _P, c_int, c_int, c_int, _P]),
+    "cg_colsum_split_workspace": (c_size_t, [c_int, c_int]),
+    "cg_colsum_split": (c_int, [POINTER(Group), _P, c_size_t, _P, ctypes.c_long, c_int, _P, c_int, _P, c_size_t, _P]),
     "cg_conv2d_wgrad_x3_ok_g": (c_int, [POINTER(ConvGeom), POINTER(Group)]),
     "cg_conv2d_wgrad_x3_g": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_size_t, _P, _P, _P, c_int, _P,
                                      c_size_t, _P]),

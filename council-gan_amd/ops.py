@@ -270,6 +270,24 @@ class _Conv2d(torch.autograd.Function):
                 dzs = split_f16_dynamic(dz, amax)
         if pre is not None and act:
             raise hip.HipError("a gradient delivered in split form only reached a layer with a fused activation")
+        # data gradients: split-precision kernel when the layer qualifies (dz gets a device-side power-of-two scale)
+        def dgrad(ci0, nci):
+            if x3_dgrad:
+                return conv_dgrad_x3(g, dzs, w, ci0, nci, grp=grp, weight=ctx.weight, wmgr=ctx.wmgr, nm=ctx.nm)
+            return conv_dgrad(g, dz, w, ci0, nci, grp=grp)
+
+        def run_dgrads():
+            d1 = dgrad(0, x.shape[1]) if ctx.needs_input_grad[0] else None
+            d2 = dgrad(x.shape[1], x2.shape[1]) if (x2 is not None and ctx.needs_input_grad[1]) else None
+            return d1, d2
+
+        dx2 = None
+        side = _companion() if (need_dw and ctx.wgrad_buf is not None) else None
+        if side is not None and WGRAD_AFTER_DGRAD:
+            # the weight gradient starts when this layer's DATA gradient has finished: it then shares the GPU with the
+            # HBM-bound passes that follow on the compute stream (norm / activation backward of the layer below), not with
+            # the equally MFMA-bound data gradient
+            dx, dx2 = run_dgrads()
         if need_dw:
             if ctx.wgrad_buf is not None:
                 # accumulate straight into the optimizer's flat gradient buffer (optim.py); grouped: every member's slice
@@ -284,7 +302,6 @@ class _Conv2d(torch.autograd.Function):
                 dw_t, acc = torch.empty_like(w), 0
                 db_t = torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if has_bias else None
                 dw, db = dw_t, db_t
-            side = _companion() if acc else None      # (gradients returned to autograd stay on the compute stream)
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record()                           # dz / its split form and the zeroed gradient buffers are ready
@@ -305,16 +322,8 @@ class _Conv2d(torch.autograd.Function):
                 for t in used:                        # stream has read them
                     if t is not None:
                         t.record_stream(side)
-        # data gradients: split-precision kernel when the layer qualifies (dz gets a device-side power-of-two scale)
-        def dgrad(ci0, nci):
-            if x3_dgrad:
-                return conv_dgrad_x3(g, dzs, w, ci0, nci, grp=grp, weight=ctx.weight, wmgr=ctx.wmgr, nm=ctx.nm)
-            return conv_dgrad(g, dz, w, ci0, nci, grp=grp)
-        if ctx.needs_input_grad[0]:
-            dx = dgrad(0, x.shape[1])
-        dx2 = None
-        if x2 is not None and ctx.needs_input_grad[1]:
-            dx2 = dgrad(x.shape[1], x2.shape[1])
+        if not (side is not None and WGRAD_AFTER_DGRAD):
+            dx, dx2 = run_dgrads()
         return (dx, dx2, dw, db) + (None,) * 14
 
 
@@ -327,6 +336,8 @@ class _Conv2d(torch.autograd.Function):
 # against 71.7 ms without (the weight-gradient kernels are MFMA-bound like the data-gradient kernels they then compete with,
 # and the batched elementwise passes are too short to hide them) -- so it is OFF unless CG_WGRAD_STREAM=1.
 WGRAD_STREAM = os.environ.get("CG_WGRAD_STREAM", "0") == "1"
+# CG_WGRAD_AFTER_DGRAD=1 (with CG_WGRAD_STREAM=1): the companion stream waits for the layer's data gradient, not just for dz
+WGRAD_AFTER_DGRAD = os.environ.get("CG_WGRAD_AFTER_DGRAD", "1") == "1"
 _companions = {}
 
 
@@ -348,6 +359,135 @@ def wgrad_join():
         torch.cuda.current_stream().wait_stream(st)
 
 
+# ------------------------------------------------------------------------------------------
+# nearest-2x upsample + 3x3 convolution as a 4x4 stride-2 transposed convolution (include/council_gan_hip.h, cg_upconv_*)
+# ------------------------------------------------------------------------------------------
+UPC_WSCALE = 0.25      # the summed-tap weights are up to 4x a weight: a quarter of the pool's scale keeps their hi halves finite
+# CG_UPCONV=0: the upsampling layers run as 3x3 convolutions that gather through the upsample (A/B switch)
+UPCONV = os.environ.get("CG_UPCONV", "1") != "0"
+_upc_groups = {}
+
+
+def _upc_group(n, elems):
+    """cg_group over the packed per-member summed-tap weights / their gradient (None for a single member)."""
+    if n <= 1:
+        return None
+    key = (n, elems)
+    g = _upc_groups.get(key)
+    if g is None:
+        g = _upc_groups[key] = hip.Group(n, 0, elems)
+    return byref(g)
+
+
+def upconv_fwd_x3(xs, weight, bias, wmgr, grp, n, stats=None):
+    """y = conv3x3(upsample2x(x)) + bias on the summed-tap weights (no autograd): xs SplitTensor [N, Cin, H, W]."""
+    lib = _lib()
+    N, C1, H, W = xs.shape
+    Cout = weight.shape[0]
+    wt = wmgr.upconv_weights(weight, grp, n)
+    if wt is None:
+        raise hip.HipError("upsample-convolution: the weight is not managed by a split-weight table")
+    g = fwd_geom(N, H, W, C1, 0, 1, 3, 3, 1, 1, Cout, 0)
+    y = torch.empty((N, Cout, 2 * H, 2 * W), dtype=torch.float32, device=xs.buf.device, memory_format=CL)
+    rows = ctypes.c_int(0)
+    sws, sbytes, rp = None, 0, None
+    if stats is not None:
+        sws = workspace(((N * 4 * H * W + 63) // 64) * Cout * 16, slot=1)
+        sbytes, rp = sws.numel(), byref(rows)
+    check(lib.cg_upconv2d_fwd_x3(byref(g), grp, xs.hi_ptr(), xs.lo, xs.scale_ptr(), ptr(wt[0]), UPC_WSCALE, wmgr.scale_ptr(),
+                                 ptr(bias), ptr(y), ptr(sws), sbytes, rp, stream()), "cg_upconv2d_fwd_x3")
+    if stats is not None and rows.value:
+        stats.append((sws, rows.value))
+    return y
+
+
+class _UpConv2d(torch.autograd.Function):
+    """conv2d(zero_pad(upsample2x(x)), weight) + bias (networks.py:385-386 + 513-516) on the summed-tap form: forward = the
+    four output-parity classes of a 4x4 stride-2 transposed convolution, data gradient = that 4x4 stride-2 convolution over
+    dz, weight gradient = its weight gradient folded back onto the nine taps.  Split-precision operands only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, wgrad_buf, bgrad_buf, stats, xsplit, wmgr, wref):
+        grp, wparam = wref
+        ctx.n = _G.n
+        y = upconv_fwd_x3(xsplit, wparam, bias, wmgr, grp, _G.n, stats)
+        ctx.xsplit, ctx.wmgr, ctx.grp, ctx.weight = xsplit, wmgr, grp, wparam
+        ctx.bufs = (wgrad_buf, bgrad_buf)
+        ctx.has_bias = bias is not None
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        N, Cin, H, W = ctx.shape
+        weight, wmgr, grp, n = ctx.weight, ctx.wmgr, ctx.grp, ctx.n
+        Cout = weight.shape[0]
+        pre = getattr(dy, "_cg_dz_split", None)
+        if pre is not None and dy._version != getattr(dy, "_cg_dz_version", dy._version):
+            raise hip.HipError("a gradient delivered in split form only was modified in place before its consumer ran")
+        if pre is not None:
+            dzs = pre
+        else:
+            amax = getattr(dy, "_cg_amax", None)
+            if amax is not None and len(amax) == 3:
+                amax = amax[:2] if dy._version == amax[2] else None
+            dzs = split_f16_dynamic(nhwc(dy), amax)
+        wt = wmgr.upconv_weights(weight, grp, n)
+        elems = lib.cg_upconv_wt_elems(Cout, Cin)
+        gF = fwd_geom(N, 2 * H, 2 * W, Cout, 0, 0, 4, 4, 2, 1, Cin, 0)       # the 4x4 stride-2 convolution over dz
+        grpF = _upc_group(n, elems)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, Cin, H, W), dtype=torch.float32, device=dzs.buf.device, memory_format=CL)
+            state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=dx.device), ctypes.c_int(0)
+            check(lib.cg_conv2d_fwd_x3_g(byref(gF), grpF, dzs.hi_ptr(), dzs.lo, ptr(wt[1]), x3_lo(1), UPC_WSCALE, wmgr.scale_ptr(),
+                                         dzs.scale_ptr(), None, ptr(dx), None, 0, None, 0, None, -1, ptr(state), byref(nslots),
+                                         stream()), "cg_conv2d_fwd_x3 (upsample-convolution data gradient)")
+            if nslots.value:
+                dx._cg_amax = (state, nslots.value, dx._version)
+        if ctx.needs_input_grad[1]:
+            wbuf, bbuf = ctx.bufs
+            if wbuf is None:
+                raise hip.HipError("upsample-convolution weight gradients need pool-backed gradient buffers")
+            xs = ctx.xsplit
+            if not lib.cg_conv2d_wgrad_x3_ok_g(byref(gF), grpF):
+                raise hip.HipError("upsample-convolution: the 4x4 stride-2 weight gradient does not take this shape")
+            dwf = torch.empty(n * elems, dtype=torch.float32, device=dzs.buf.device)
+            ws = workspace(lib.cg_conv2d_wgrad_workspace_g(byref(gF), grpF))
+            check(lib.cg_conv2d_wgrad_x3_g(byref(gF), grpF, dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), xs.hi_ptr(), xs.lo,
+                                           xs.scale_ptr(), ptr(dwf), None, 0, ptr(ws), ws.numel(), stream()),
+                  "cg_conv2d_wgrad_x3 (upsample-convolution)")
+            check(lib.cg_upconv_fold_dw(grp, ptr(dwf), ptr(wbuf), Cout, Cin, 1, stream()), "cg_upconv_fold_dw")
+            wbuf._cg_touched = True
+            if ctx.has_bias and bbuf is not None:
+                ws2 = workspace(lib.cg_colsum_split_workspace(Cout, n), slot=2)
+                check(lib.cg_colsum_split(grp, dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), N * 4 * H * W, Cout, ptr(bbuf), 1, ptr(ws2),
+                                          ws2.numel(), stream()), "cg_colsum_split")
+                bbuf._cg_touched = True
+        return (dx, dw, db) + (None,) * 6
+
+
+_upc_ok_cache = {}
+
+
+def _upconv_ok(shape, weight, stride, pad, act, x2, wmgr):
+    """Does this upsample + convolution layer take the summed-tap path?  `shape` = (N, Cin, H, W) of the source."""
+    if not (UPCONV and X3_FORWARD and X3_BACKWARD and wmgr is not None and x2 is None and weight.dim() == 4
+            and tuple(weight.shape[2:]) == (3, 3) and stride == 1 and pad == 1 and ACT[act] == 0
+            and weight.shape[0] % 32 == 0 and weight.shape[1] % 32 == 0 and 256 % weight.shape[0] == 0
+            and getattr(weight, "_cg_grad", None) is not None and x3_interleaved()):
+        return False
+    N, Cin, H, W = shape
+    Cout, n = weight.shape[0], _G.n
+    key = (N, Cin, H, W, Cout, n)
+    ok = _upc_ok_cache.get(key)
+    if ok is None:       # the weight gradient of the 4x4 stride-2 convolution over dz must run on the split-precision kernels
+        gF = fwd_geom(N, 2 * H, 2 * W, Cout, 0, 0, 4, 4, 2, 1, Cin, 0)
+        ok = _upc_ok_cache[key] = bool(_lib().cg_conv2d_wgrad_x3_ok_g(byref(gF), _upc_group(n, 16 * Cout * Cin)))
+    return ok
+
+
 X3_FORWARD = True     # module switches (Council_Trainer sets them from the config): split-precision forward convolutions,
 X3_BACKWARD = True    # split-precision data gradients, dynamic (device-scaled) splitting of un-normalised conv inputs
 X3_DYNAMIC_INPUT = True
@@ -362,6 +502,17 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=
     split form travels as the `_cg_split` attribute of `x` (set by the op that produced it), and with `want_split`
     the output gets one for the next convolution."""
     xsplit = wsplit = out_split = None
+    if upsample and _upconv_ok(tuple(x.shape), weight, stride, pad, act, x2, wmgr) and wmgr.get(weight) is not None:
+        xsplit = getattr(x, "_cg_split", None)
+        if xsplit is None:
+            with torch.no_grad():
+                xsplit = split_f16_dynamic(x.detach(), getattr(x, "_cg_amax", None))
+        y = _UpConv2d.apply(x, weight, bias, getattr(weight, "_cg_grad", None),
+                            getattr(bias, "_cg_grad", None) if bias is not None else None, stats, xsplit, wmgr,
+                            (_grp(weight), weight))
+        if stats is not None:
+            y._cg_dz_split_ok = True      # both gradients of this layer take dz in split form
+        return y
     if X3_FORWARD and wmgr is not None and x2 is None and x3_eligible(x.shape[1], 0) and weight.dim() == 4:
         # inputs whose producer emitted the split form are instance-normalised (or one fused conv+ReLU away from it),
         # i.e. O(1) activations inside fp16's accurate range, and travel unscaled; any other input is split here
@@ -712,6 +863,24 @@ class SplitWeights:
             wt = torch.empty(2 * n * elems, dtype=torch.float16, device=w.device)
             check(lib.cg_conv2d_dgrad_x3_prep(byref(g), grp, ptr(w), ci0, nci, 1.0, self.scale_ptr(), ptr(wt),
                                               wt.numel() * 2, stream()), "cg_conv2d_dgrad_x3_prep")
+            self._dgrad[key] = wt
+        return wt
+
+    def upconv_weights(self, weight, grp, n):
+        """(wt_fwd, wt_bwd): the summed-tap {hi, lo} weights of an upsample + 3x3 layer (cg_upconv_prep_x3) for the current
+        weight version and member scope -- one launch pair per (layer, version)."""
+        if not self.refresh() or id(weight) not in self.views:
+            return None
+        key = (id(weight), 'up', n)
+        wt = self._dgrad.get(key)
+        if wt is None:
+            lib = _lib()
+            Cout, Cin = weight.shape[0], weight.shape[1]
+            elems = lib.cg_upconv_wt_elems(Cout, Cin)
+            wt = (torch.empty(2 * n * elems, dtype=torch.float16, device=weight.device),
+                  torch.empty(2 * n * elems, dtype=torch.float16, device=weight.device))
+            check(lib.cg_upconv_prep_x3(grp, ptr(nhwc(weight)), Cout, Cin, UPC_WSCALE, self.scale_ptr(), ptr(wt[0]), ptr(wt[1]),
+                                        stream()), "cg_upconv_prep_x3")
             self._dgrad[key] = wt
         return wt
 

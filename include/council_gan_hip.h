@@ -170,6 +170,33 @@ int cg_conv2d_dgrad_x3_prep(const cg_conv_geom* g, const cg_group* group, const 
 int cg_conv2d_dgrad_x3_run(const cg_conv_geom* g, const cg_group* group, const void* dz_split, size_t dz_lo_elems,
                            const float* dz_scale_dev, const void* wt, float w_scale, const float* w_scale_dev, int ci0,
                            int nci, float* dx, float* amax_state, int* amax_nslots, cg_stream_t stream);
+/* ---- nearest-2x upsample + 3x3 convolution (nn.Upsample(scale_factor=2) in front of a Conv2dBlock, networks.py:385-386,
+ *      513-516) evaluated as the 4x4 stride-2 TRANSPOSED convolution it is: the 3x3 taps that read the same source pixel are
+ *      added up first (fp32), 16 effective taps per 4 output pixels instead of 36 -- 2.25x fewer multiply-adds, results equal
+ *      up to fp32 rounding of the tap sums.  W_F[u][v] = sum_{kh in S(u), kw in S(v)} W[kh][kw], S(0) = {2}, S(1) = {1,2},
+ *      S(2) = {0,1}, S(3) = {0}.
+ *   cg_upconv_prep_x3:   w [Cout][3][3][Cin] fp32 of every member -> {hi, lo} planes of scale * W_F, scale = w_scale (x the
+ *                        device value *w_scale_dev when given), in two layouts of cg_upconv_wt_elems(Cout, Cin) elements per
+ *                        member (4 bytes each): wt_fwd = the four output-parity classes [cls][Cout][2x2 taps][Cin] the forward
+ *                        reads, wt_bwd = [Cin][4][4][Cout], the weight of the 4x4 stride-2 pad-1 convolution over dz that IS the
+ *                        data gradient (run it with cg_conv2d_fwd_x3_g; its weight gradient with cg_conv2d_wgrad_x3_g, input dz,
+ *                        output gradient x, gives dW_F).  Either output may be NULL.
+ *   cg_upconv2d_fwd_x3:  y = conv(upsample2x(x)) + bias from x in {hi, lo} form and wt_fwd; g = the geometry of the 3x3 layer
+ *                        on the upsampled source (up = 1).  stats / rows_per_partial as cg_conv2d_fwd_stats.
+ *   cg_upconv_fold_dw:   dw[co][kh][kw][ci] (+)= sum_{u: kh in S(u), v: kw in S(v)} dwf[ci][u][v][co]   (members: dwf packed,
+ *                        dw at group->stride).
+ *   cg_colsum_split:     db[c] (+)= sum over rows of a {hi, lo} tensor [rows_total][C] / *scale_dev -- the bias gradient of a layer
+ *                        whose dz exists in split form only (rows_total = all members' rows, member-major). */
+size_t cg_upconv_wt_elems(int Cout, int Cin);
+int cg_upconv_prep_x3(const cg_group* group, const float* w, int Cout, int Cin, float w_scale, const float* w_scale_dev,
+                      void* wt_fwd, void* wt_bwd, cg_stream_t stream);
+int cg_upconv2d_fwd_x3(const cg_conv_geom* g, const cg_group* group, const void* x_split, size_t x_lo_elems,
+                       const float* x_scale_dev, const void* wt_fwd, float w_scale, const float* w_scale_dev, const float* bias,
+                       float* y, double* stats, size_t stats_bytes, int* rows_per_partial, cg_stream_t stream);
+int cg_upconv_fold_dw(const cg_group* group, const float* dwf, float* dw, int Cout, int Cin, int accumulate, cg_stream_t stream);
+size_t cg_colsum_split_workspace(int C, int nmember);
+int cg_colsum_split(const cg_group* group, const void* z_split, size_t lo_elems, const float* scale_dev, long rows_total, int C,
+                    float* db, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream);
 /* split-precision weight gradient: cg_conv2d_wgrad with x and dz given in {hi, lo} form (+ device-side scales,
  * NULL = 1).  cg_conv2d_wgrad_x3_ok(g) != 0 iff the layer qualifies (one source, every k-tile inside one tap,
  * channel counts multiples of 32, power-of-two output plane); workspace as cg_conv2d_wgrad_workspace(g). */

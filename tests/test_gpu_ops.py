@@ -1161,3 +1161,56 @@ def test_split_precision_weight_gradient_multi_tap_tiles(cga, shape):
         t.wgrad_x3_multitap = prev
         hip.check(lib.cg_tuning_set(t), "cg_tuning_set")
     _wgrad_tile_case(cga, shape, switch, restore)
+
+
+@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("shape", [(128, 64, 16), (256, 128, 16), (64, 32, 32)], ids=["128to64", "256to128", "64to32"])
+def test_upsample_conv_as_transposed_conv(cga, shape, n):
+    """nn.Upsample(2x nearest) + ZeroPad2d(1) + Conv2d(3x3) (networks.py:385-386, 513-516) on the summed-tap form
+    (cg_upconv_*: four output-parity classes of a 4x4 stride-2 transposed convolution; data gradient = a 4x4 stride-2
+    convolution over dz; weight gradient folded back onto the nine taps) against fp64 torch on the upsampled tensor:
+    forward, instance-norm partial sums from the epilogue, data / weight / bias gradients, n members per launch."""
+    from council_gan_amd import ops
+    from council_gan_amd.optim import ParamPool
+    Cin, Cout, H = shape
+    B = 2
+    torch.manual_seed(11 + Cin + n)
+    convs = [torch.nn.Conv2d(Cin, Cout, 3, 1, bias=True) for _ in range(n)]
+    for k, c in enumerate(convs):
+        with torch.no_grad():
+            c.bias.normal_()
+            c.weight.mul_(1.0 + 0.5 * k)
+    w64 = [c.weight.detach().double().clone() for c in convs]
+    b64 = [c.bias.detach().double().clone() for c in convs]
+    pool = ParamPool([cga.FlatAdam(list(c.parameters()), lr=1e-4) for c in convs])
+    pool.materialize('cuda')
+    mgr = ops.SplitWeights(pool)
+    x = cl(torch.randn(n * B, Cin, H, H).cuda())
+    gy = cl(torch.randn(n * B, Cout, 2 * H, 2 * H).cuda())
+    saved = (ops.X3_FORWARD, ops.X3_BACKWARD, ops.X3_DYNAMIC_INPUT)
+    ops.X3_FORWARD = ops.X3_BACKWARD = ops.X3_DYNAMIC_INPUT = True
+    try:
+        xi = x.clone().requires_grad_(True)
+        stats = []
+        with ops.members(n):
+            taken = ops._upconv_ok(tuple(x.shape), convs[0].weight, 1, 1, "none", None, mgr)
+            assert taken == (Cout >= 64), "the shipped widths (256 -> 128, 128 -> 64) must take the summed-tap path"
+            y = ops.conv2d(xi, convs[0].weight, convs[0].bias, 1, 1, "none", upsample=True, stats=stats, wmgr=mgr)
+            assert stats, "the epilogue should have produced the instance-norm partial sums"
+            yn = ops.instance_norm(y, act="relu", stats=stats)
+        y.backward(gy, retain_graph=True)
+        torch.cuda.synchronize()
+    finally:
+        ops.X3_FORWARD, ops.X3_BACKWARD, ops.X3_DYNAMIC_INPUT = saved
+    for m in range(n):
+        rows = slice(m * B, (m + 1) * B)
+        xr = x[rows].detach().double().cpu().requires_grad_(True)
+        wr, br = w64[m].clone().requires_grad_(True), b64[m].clone().requires_grad_(True)
+        yr = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), wr, br, padding=1)
+        yr.backward(gy[rows].double().cpu())
+        assert rel(y[rows], yr) < TOL, ("forward", m)
+        ynr = F.relu(F.instance_norm(yr.detach()))
+        assert rel(yn[rows], ynr) < 1e-4, ("instance norm on the epilogue's partial sums", m)
+        assert rel(xi.grad[rows], xr.grad) < TOL, ("data gradient", m)
+        assert rel(convs[m].weight._cg_grad, wr.grad) < TOL, ("weight gradient", m)
+        assert rel(convs[m].bias._cg_grad, br.grad) < TOL, ("bias gradient", m)
