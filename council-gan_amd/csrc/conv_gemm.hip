@@ -1685,8 +1685,8 @@ bool pipe_ok(const cg_conv_geom* g, int K) {
 }
 
 // ---- thin-input layers (conv_fwd_thin_kernel) -----------------------------------------------------------------------
-// CG_FWD_THIN=1 in the environment / cg_conv2d_fwd_thin(1): layers that match a compiled (KH, KW, channels, stride) variant
-// run on the spatial-tile kernel (tile configuration 40); off by default until measured in the step.
+// Layers that match a compiled (KH, KW, channels, stride) variant run on the spatial-tile kernel (tile configuration 40);
+// on by default since round 3 (measured in the step), CG_FWD_THIN=0 in the environment / cg_conv2d_fwd_thin(0) turns it off.
 static bool fwd_thin_on() { return tune().fwd_thin != 0; }
 
 struct ThinVariant { int kh, kw, ct, s; };

@@ -863,7 +863,8 @@ extern "C" int cg_instnorm_bwd(const float* dy, const float* x, const float* mea
 
 // ---- instance-norm backward that hands dx to the split-precision convolution kernels directly ----------------------
 static bool bwd_split_ok(int N, int HW, int C) {
-    return CG_X3_INTERLEAVE && (C & 31) == 0 && (256 % (C >> 3)) == 0 && (size_t)HW * C < (size_t)0x7fffffff && N >= 1;
+    // quad_ok: the reduction pass (in_bwd_partial_q) walks the rows with 256 / (C / 4) lanes per row -- C <= 1024
+    return CG_X3_INTERLEAVE && (C & 31) == 0 && (256 % (C >> 3)) == 0 && quad_ok(C) && (size_t)HW * C < (size_t)0x7fffffff && N >= 1;
 }
 extern "C" size_t cg_instnorm_bwd_split_workspace(int N, int HW, int C) {
     if (N <= 0 || HW <= 0 || C <= 0 || !bwd_split_ok(N, HW, C)) return 0;      // 0: this shape takes cg_instnorm_bwd

@@ -44,10 +44,10 @@ class AdaptiveInstanceNorm2d(nn.Module):
         self.register_buffer('running_mean', torch.zeros(num_features))
         self.register_buffer('running_var', torch.ones(num_features))
 
-    def forward(self, x, act='none', residual=None, stats=None, want_split=False):
+    def forward(self, x, act='none', residual=None, stats=None, want_split=False, want_f32=True):
         assert self.params is not None, "Please assign weight and bias before calling AdaIN!"
         return ops.adain(x, self.params, self.goff, self.boff, act=act, residual=residual, eps=self.eps, stats=stats,
-                         want_split=want_split)
+                         want_split=want_split, want_f32=want_f32)
 
     def __repr__(self):
         return self.__class__.__name__ + '(' + str(self.num_features) + ')'
@@ -105,7 +105,9 @@ class Conv2dBlock(nn.Module):
         self.activation_type = activation
         self.conv = nn.Conv2d(input_dim, output_dim, kernel_size, stride, bias=self.use_bias)
 
-    def forward(self, x, x2=None, upsample=False, residual=None):
+    def forward(self, x, x2=None, upsample=False, residual=None, want_f32=True):
+        # want_f32=False: the caller knows that the only consumer of this block's output is a convolution that reads the
+        # {hi, lo} planes the norm emits -- the fp32 copy is then not written (split-precision datapath only)
         act = self.activation_type
         fused_act = act if self.norm is None else 'none'
         stats = [] if self.norm_type in ('in', 'adain') else None     # conv epilogue -> norm statistics hand-off
@@ -116,9 +118,10 @@ class Conv2dBlock(nn.Module):
         y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, fused_act, x2=x2,
                        upsample=upsample, stats=stats, wmgr=wmgr, want_split=want_split)
         if self.norm_type == 'in':
-            y = ops.instance_norm(y, act=act, residual=residual, eps=self.norm.eps, stats=stats, want_split=want_split)
+            y = ops.instance_norm(y, act=act, residual=residual, eps=self.norm.eps, stats=stats, want_split=want_split,
+                                  want_f32=want_f32)
         elif self.norm_type == 'adain':
-            y = self.norm(y, act=act, residual=residual, stats=stats, want_split=want_split)
+            y = self.norm(y, act=act, residual=residual, stats=stats, want_split=want_split, want_f32=want_f32)
         elif self.norm_type == 'ln':
             y = ops.activation(self.norm(y), act)
             if residual is not None:
@@ -168,7 +171,7 @@ class ResBlock(nn.Module):
         self.model = nn.Sequential(*model)
 
     def forward(self, x):
-        return self.model[1](self.model[0](x), residual=x)
+        return self.model[1](self.model[0](x, want_f32=False), residual=x)
 
 
 class LinearBlock(nn.Module):
@@ -263,8 +266,12 @@ class ContentEncoder(nn.Module):
         self.output_dim = dim
 
     def forward(self, x):
-        for m in self.model:
-            x = m(x)
+        mods = list(self.model)
+        for i, m in enumerate(mods):
+            if isinstance(m, Conv2dBlock):      # consumed by the next convolution only (the last one also feeds a skip connection)
+                x = m(x, want_f32=not (i + 1 < len(mods) and isinstance(mods[i + 1], Conv2dBlock)))
+            else:
+                x = m(x)
         return x
 
 
@@ -325,7 +332,8 @@ class Decoder_V2_atten(nn.Module):
             head = [self.model[k].conv for k in range(len(self.model) - 3, len(self.model))]
             wmgr = getattr(self.model[len(self.model) - 1], '_cg_wmgr', None)
             fused_ok = ops.FUSED_HEAD and wmgr is not None and self.output_dim == 3 and self.num_of_mask_dim_to_add == 3 \
-                and head[0].in_channels == 64 and all(self.model[k].norm is None for k in range(len(self.model) - 3, len(self.model)))
+                and head[0].in_channels == 64 and all(self.model[k].norm is None for k in range(len(self.model) - 3, len(self.model))) \
+                and [self.model[k].activation_type for k in range(len(self.model) - 3, len(self.model))] == ['relu', 'relu', 'tanh']      # what head_fwd_x3_kernel computes
             y, ys, i = self._trunk_split(x, want_f32=not fused_ok)
             if fused_ok:
                 out = ops.decoder_head_x3(ys, head, wmgr, im_in, self.output_dim, self.num_of_mask_dim_to_add)
@@ -338,9 +346,9 @@ class Decoder_V2_atten(nn.Module):
         else:
             y = self.model[0](x)
             i = 1
-            for _ in range(self.n_upsample):
-                y = self.model[i + 1](y, upsample=True)
-                y = self.model[i + 2](y)
+            for _ in range(self.n_upsample):          # each output is read by the next convolution only
+                y = self.model[i + 1](y, upsample=True, want_f32=False)
+                y = self.model[i + 2](y, want_f32=False)
                 i += 3
         y = self.model[i](y)
         y = self.model[i + 1](y)

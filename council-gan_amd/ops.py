@@ -167,7 +167,7 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x2, weight, bias, wgrad_buf, bgrad_buf, stride, pad, act, up, stats, xsplit=None, wsplit=None,
-                out_split=None, amax_out=None, wmgr=None, wref=None, dz_split_ok=None):
+                out_split=None, amax_out=None, wmgr=None, wref=None, dz_split_ok=None, x_no_f32=False):
         # wref = (cg_group or None, the Parameter object): resolved by the caller, where the tensor still carries its
         # Python attributes
         lib = _lib()
@@ -215,6 +215,7 @@ class _Conv2d(torch.autograd.Function):
             stats.append((sws, rows.value))
         ctx.save_for_backward(x, x2, w, y if act else None)
         ctx.xsplit = xsplit if (xsplit is not None and wsplit is not None) else None     # reused by the x3 weight gradient
+        ctx.x_no_f32 = bool(x_no_f32)
         ctx.g, ctx.meta = g, (KH, KW, stride, pad, act, int(up), bias is not None)
         ctx.wgrad_buf, ctx.bgrad_buf = wgrad_buf, bgrad_buf
         ctx.grp, ctx.weight, ctx.wmgr, ctx.nm = grp, wparam, wmgr, _G.n      # backward may run outside the members() scope
@@ -253,6 +254,8 @@ class _Conv2d(torch.autograd.Function):
             (grp is None or (ctx.wmgr is not None and ctx.weight is not None))
         x3_wgrad = X3_BACKWARD and need_dw and ctx.xsplit is not None and bool(lib.cg_conv2d_wgrad_x3_ok_g(byref(g), grp))
         fp32_needed = (need_dx and not x3_dgrad) or (need_dw and not x3_wgrad)
+        if ctx.x_no_f32 and need_dw and not x3_wgrad:
+            raise hip.HipError("the weight gradient of this layer reads its input in fp32, but the input exists in split form only")
         dzs = None
         if act:
             if x3_dgrad or x3_wgrad:
@@ -324,7 +327,7 @@ class _Conv2d(torch.autograd.Function):
                         t.record_stream(side)
         if not (side is not None and WGRAD_AFTER_DGRAD):
             dx, dx2 = run_dgrads()
-        return (dx, dx2, dw, db) + (None,) * 14
+        return (dx, dx2, dw, db) + (None,) * 15
 
 
 # Weight gradients leave the chain of dependent backward kernels: nothing downstream of a layer's backward needs its dW
@@ -502,6 +505,7 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=
     split form travels as the `_cg_split` attribute of `x` (set by the op that produced it), and with `want_split`
     the output gets one for the next convolution."""
     xsplit = wsplit = out_split = None
+    no_f32 = bool(getattr(x, "_cg_no_f32", False))
     if upsample and _upconv_ok(tuple(x.shape), weight, stride, pad, act, x2, wmgr) and wmgr.get(weight) is not None:
         xsplit = getattr(x, "_cg_split", None)
         if xsplit is None:
@@ -532,11 +536,13 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=
     # one's epilogue measure them (stats is None: no instance norm in between)
     amax_out = [] if (X3_FORWARD and X3_DYNAMIC_INPUT and stats is None and out_split is None and weight.dim() == 4 and
                       weight.shape[0] % 32 == 0) else None
+    if no_f32 and (xsplit is None or wsplit is None or x.requires_grad and not X3_BACKWARD):
+        raise hip.HipError("an activation produced in split form only reached a convolution that reads fp32")
     dz_ok = [] if (stats is not None and X3_BACKWARD and xsplit is not None) else None      # a norm follows
     y = _Conv2d.apply(x, x2, weight, bias, getattr(weight, "_cg_grad", None),
                       getattr(bias, "_cg_grad", None) if bias is not None else None,
                       int(stride), int(pad), ACT[act], bool(upsample), stats, xsplit, wsplit, out_split, amax_out, wmgr,
-                      (_grp(weight), weight), dz_ok)
+                      (_grp(weight), weight), dz_ok, no_f32)
     if dz_ok:
         y._cg_dz_split_ok = True
     if out_split:
@@ -564,7 +570,7 @@ class _InstNormAct(torch.autograd.Function):
     of `params` ([N, P], the MLP output, networks.py:303-312) or absent (plain nn.InstanceNorm2d)."""
 
     @staticmethod
-    def forward(ctx, x, params, goff, boff, residual, act, eps, stats, out_split=None, dx_split_only=False):
+    def forward(ctx, x, params, goff, boff, residual, act, eps, stats, out_split=None, dx_split_only=False, no_f32=False):
         lib = _lib()
         ctx.dx_split_only = bool(dx_split_only)
         x, residual = nhwc(x), nhwc(residual)
@@ -590,9 +596,13 @@ class _InstNormAct(torch.autograd.Function):
             gp, bp, gs = None, None, C
         if out_split is not None and (C & 3) == 0 and 256 % (C >> 2) == 0:
             ysp = SplitTensor(torch.empty(2 * y.numel(), dtype=torch.float16, device=y.device), y.shape)
-            check(lib.cg_instnorm_apply_split(ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(residual), ptr(y), ysp.hi_ptr(),
-                                              ysp.lo, N, HW, C, act, stream()), "cg_instnorm_apply_split")
+            # no_f32: every consumer reads the {hi, lo} planes (a split-precision convolution, forward and weight gradient) --
+            # the fp32 copy is not written; `y` stays an uninitialised carrier for the autograd graph (marked by the caller)
+            check(lib.cg_instnorm_apply_split(ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(residual), None if no_f32 else ptr(y),
+                                              ysp.hi_ptr(), ysp.lo, N, HW, C, act, stream()), "cg_instnorm_apply_split")
             out_split.append(ysp)
+            if no_f32:
+                out_split.append(True)
         else:
             check(lib.cg_instnorm_apply(ptr(x), ptr(mean), ptr(rstd), gp, bp, gs, ptr(residual), ptr(y), N, HW, C, act,
                                         stream()), "cg_instnorm_apply")
@@ -641,28 +651,35 @@ class _InstNormAct(torch.autograd.Function):
                                       ptr(ws), ws.numel(), ptr(state), byref(nslots), stream()), "cg_instnorm_bwd")
             if nslots.value:
                 dx._cg_amax = (state, nslots.value, dx._version)     # the conv before this norm splits dx without measuring it again
-        return dx, dparams, None, None, (dy if has_res else None), None, None, None, None, None
+        return dx, dparams, None, None, (dy if has_res else None), None, None, None, None, None, None
 
 
 # CG_DX_SPLIT=0: instance-norm backward always writes fp32 dx and the convolution splits it in a pass of its own (A/B switch)
 DX_SPLIT = os.environ.get("CG_DX_SPLIT", "1") != "0"
 
 
-def _norm_apply(x, params, goff, boff, residual, act, eps, stats, want_split):
+# CG_NORM_NO_F32=0: the norm apply always writes the fp32 activation next to its {hi, lo} planes (A/B switch)
+NORM_NO_F32 = os.environ.get("CG_NORM_NO_F32", "1") != "0"
+
+
+def _norm_apply(x, params, goff, boff, residual, act, eps, stats, want_split, want_f32=True):
     out_split = [] if (want_split and X3_FORWARD) else None
     y = _InstNormAct.apply(x, params, goff, boff, residual, ACT[act], float(eps), stats, out_split,
-                           bool(getattr(x, "_cg_dz_split_ok", False)))
+                           bool(getattr(x, "_cg_dz_split_ok", False)),
+                           bool(out_split is not None and not want_f32 and NORM_NO_F32 and X3_BACKWARD))
     if out_split:
         y._cg_split = out_split[0]
+        if len(out_split) > 1:
+            y._cg_no_f32 = True      # fp32 values never written: only split-precision kernels may consume this tensor
     return y
 
 
-def instance_norm(x, act="none", residual=None, eps=1e-5, stats=None, want_split=False):
-    return _norm_apply(x, None, 0, 0, residual, act, eps, stats, want_split)
+def instance_norm(x, act="none", residual=None, eps=1e-5, stats=None, want_split=False, want_f32=True):
+    return _norm_apply(x, None, 0, 0, residual, act, eps, stats, want_split, want_f32)
 
 
-def adain(x, params, goff, boff, act="none", residual=None, eps=1e-5, stats=None, want_split=False):
-    return _norm_apply(x, params, int(goff), int(boff), residual, act, eps, stats, want_split)
+def adain(x, params, goff, boff, act="none", residual=None, eps=1e-5, stats=None, want_split=False, want_f32=True):
+    return _norm_apply(x, params, int(goff), int(boff), residual, act, eps, stats, want_split, want_f32)
 
 
 class _Activation(torch.autograd.Function):

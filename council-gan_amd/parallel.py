@@ -78,6 +78,7 @@ def native_comm(group, ranks):
 class CouncilShard:
     def __init__(self, council_size, rank=0, world_size=1, group=None, member_group=None, slice_group=None):
         self.member_comm = self.slice_comm = None     # C-ABI communicators (use_native_collectives)
+        self.timing = None          # a list: exchange_flat appends a (start, end) event pair per exchange (bench.py N > 1)
         self.council_size = council_size
         self.rank = rank
         self.world_size = world_size
@@ -187,7 +188,14 @@ class CouncilShard:
             return local
         send = local.permute(0, 2, 3, 1).contiguous()                 # the PHYSICAL (NHWC) layout, untouched
         recv = torch.empty((self.slice_ranks,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+        ev = None
+        if self.timing is not None and send.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         _all_gather(recv, send, self.slice_group, self.slice_comm)
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
         return recv.view((-1,) + tuple(send.shape[1:])).permute(0, 3, 1, 2)
 
     def gather_scalars(self, values):

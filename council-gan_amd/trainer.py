@@ -276,7 +276,9 @@ class Council_Trainer(nn.Module):
         # Default: on when the council is sharded over several ranks (a rank with one member has ~20 ms of GPU work per
         # iteration against ~15 ms of eager enqueue), off on a single GPU (GPU-bound either way; eager keeps the overlap of
         # the two discriminator-side updates: 68.5 vs 69.1 ms per step, profiles/r03_g_*).
-        dflt = '1' if (self.shard.world_size > 1 and self.shard.dp == 1) else '0'
+        # ... and on for a single gen / dis pair (council 1: a short, enqueue-bound step with no second update to overlap:
+        # 8.89 eager vs 8.44 ms replayed at 128x128 batch 8, profiles/r03_s_graph_vs_eager.txt)
+        dflt = '1' if ((self.shard.world_size > 1 and self.shard.dp == 1) or self.council_size == 1) else '0'
         self._graph_mode = str(self._hp_cfg.get('cg_graph', os.environ.get('CG_GRAPH', dflt))) == '1' and self.shard.dp == 1
         self._graph_warmup = max(1, int(os.environ.get('CG_GRAPH_WARMUP', '1')))
         self._hin = HostInputs(dev)
@@ -416,7 +418,7 @@ class Council_Trainer(nn.Module):
         """The batch repeated once per member of a launch (member-major): every member sees the same images."""
         if g == 1:
             return x
-        key = (id(x), g)
+        key = (id(x), x._version, g)
         ent = self._rep_cache.get(key)
         if ent is None or ent[0] is not x:
             if len(self._rep_cache) > 8:
@@ -429,7 +431,9 @@ class Council_Trainer(nn.Module):
         """Content codes of the members of `grp` for batch x (the member-major repetition of the NHWC device copy from
         _img).  Encoded once per (batch, generator weights) with the autograd tape attached; the discriminator updates
         use it detached, gen_update back-propagates through it (and drops it, the tape being consumed)."""
-        key = (id(x), self._weights_version(d, grp))
+        # the batch is identified by object AND version: in graph mode every batch lands in the same static buffer (copy_ bumps
+        # its version), so two discriminator updates on different batches must not share content codes
+        key = (id(x), x._version, self._weights_version(d, grp))
         slot = (d, grp[0], len(grp))
         ent = self._enc_cache.get(slot)
         if ent is None or ent[0] != key or ent[1] is not x:
@@ -505,6 +509,11 @@ class Council_Trainer(nn.Module):
             # call order), the rest of that iteration runs eagerly too (self._iter_eager, reset by dis_update).
             seg = self._segs.get(key)
             if seg is None:
+                # a new (shapes, schedule flags, hyper-parameters) key of this kind replaces the old one: its graph and the
+                # activation pool the graph owns are released instead of staying resident next to the new capture
+                for k in [k for k in self._segs if k[0] == key[0]]:
+                    old = self._segs.pop(k)
+                    old.graph, old.out, old.effects = None, None, []
                 seg = self._segs[key] = Segment()
             if seg.graph is not None and seg.generation != self._hin.generation:
                 seg.graph, seg.warm = None, 0                      # a static input buffer moved: capture again
@@ -557,6 +566,7 @@ class Council_Trainer(nn.Module):
                             setattr(self, k, v)
                         return
                     seg.graph, seg.generation = g, self._hin.generation
+                    self._n_captures = self.__dict__.get('_n_captures', 0) + 1
                 seg.graph.replay()
                 for fn in seg.effects:
                     fn()

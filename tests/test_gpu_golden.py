@@ -200,7 +200,7 @@ def test_two_iterations_vs_reference(cga, name):
                     # value is off its fp64 value by more than 1e-3 on some fixtures, so this criterion is judged
                     # like the generator gradients -- distance to the fp64 oracle, at most twice the reference's
                     r64 = lossvec(otr64.loss_mask_zero_one[d])
-                    tol = np.maximum(np.maximum(LT, P.MASK_ZO_TOL) * np.abs(r64), 2 * np.abs(ref - r64)) + 1e-7      # parity_util.MASK_ZO_TOL
+                    tol = P.mask_zo_tol(ref, r64, LT)
                     assert np.all(np.abs(mine - r64) <= tol), (nm, d, mine, ref, r64)
                 else:
                     np.testing.assert_allclose(mine, ref, rtol=LT, atol=1e-7)

@@ -35,7 +35,7 @@ def _tiny(name, council, batch):
     return cfg
 
 
-def _run(cga, cfg, graph, iters, size, group_max=None, overlap=None, expect_graph_mode_after=None):
+def _run(cga, cfg, graph, iters, size, group_max=None, overlap=None, expect_graph_mode_after=None, dis_twice=False):
     c = copy.deepcopy(cfg)
     c['cg_graph'] = '1' if graph else '0'
     O.seed_all(11)
@@ -53,6 +53,9 @@ def _run(cga, cfg, graph, iters, size, group_max=None, overlap=None, expect_grap
             x_a, x_b = O.synthetic_batch(c['batch_size'], size, seed=7 + it)
             x_a, x_b = x_a.cuda(), x_b.cuda()
         c['iteration'] = 60000 + it
+        if dis_twice:          # train.py:241-246 with dis.numberOf_dis_relative_iteration = 2: an extra discriminator update on
+            y_a, y_b = O.synthetic_batch(c['batch_size'], size, seed=900 + it)      # ANOTHER batch before this iteration's three
+            tr.dis_update(y_a.cuda(), y_b.cuda(), c)
         tr.dis_update(x_a, x_b, c)
         tr.dis_council_update(x_a, x_b, c)
         tr.gen_update(x_a, x_b, c, c['iteration'])
@@ -75,7 +78,8 @@ def _run(cga, cfg, graph, iters, size, group_max=None, overlap=None, expect_grap
                     w[(d, kind, i, k)] = v.detach().cpu().clone()
     steps = [list(o._steps) for o in tr.gen_opt_s]
     ring = {d: list(tr._ring_pos[d]) for d in tr._dirs}
-    captured = sum(1 for s in tr._segs.values() if s.graph is not None)
+    captured = tr.__dict__.get('_n_captures', 0)      # captures over the run (a new key of a kind evicts the old graph)
+    assert sum(1 for s in tr._segs.values() if s.graph is not None) <= 4
     if expect_graph_mode_after is not None:
         assert tr._graph_mode == expect_graph_mode_after
     del tr
@@ -129,6 +133,24 @@ def test_a_failed_capture_falls_back_to_eager(cga, fail_at, monkeypatch):
     assert uses[0] == fail_at
     assert e_rows == g_rows
     assert e_steps == g_steps and e_ring == g_ring
+    for k in e_w:
+        assert torch.equal(e_w[k], g_w[k]), k
+
+
+def test_graph_mode_two_discriminator_updates_on_different_batches(cga):
+    """dis.numberOf_dis_relative_iteration > 1 (train.py:241-246): two discriminator updates in a row, each on its own batch.
+    In graph mode both batches land in the same static buffer; the content-code cache is keyed on the buffer's version, so
+    the second update encodes ITS batch (it used to reuse the first batch's codes).  One member per launch -- the
+    configuration of a rank that holds one member -- and bit-identical to the eager run."""
+    cfg = _tiny("male2female_council_folder.yaml", 2, 2)
+    try:
+        e_rows, e_w, e_steps, _, _ = _run(cga, cfg, False, 4, 64, 1, dis_twice=True)
+        g_rows, g_w, g_steps, _, g_cap = _run(cga, cfg, True, 4, 64, 1, dis_twice=True)
+    finally:
+        cga.ops.X3_FORWARD = cga.ops.X3_BACKWARD = cga.ops.X3_DYNAMIC_INPUT = True
+    assert g_cap >= 4
+    assert e_rows == g_rows, [(a, b) for a, b in zip(e_rows, g_rows) if a != b][:2]
+    assert e_steps == g_steps
     for k in e_w:
         assert torch.equal(e_w[k], g_w[k]), k
 

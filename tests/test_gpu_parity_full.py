@@ -72,6 +72,17 @@ def test_bench_shape_iteration_vs_oracle(cga):
     assert any(k.startswith("conv_wgrad_x3t_kernel<256,128") for k in ran), sorted(ran)
 
 
+@pytest.mark.slow
+def test_bench_batch_iteration_vs_fp32_oracle(cga):
+    """The benchmark's OWN batch (VERDICT r3 item 3 ii): BASELINE.json configs[2] at batch 4 -- 16 samples per member-batched
+    launch, batch-4 offsets, launches with more than 1024 blocks (the folded amax slots), the 5 B-sample council batches at
+    256^2 -- one whole iteration against the fp32 oracle alone (its fp64 twin at this size would double two minutes of CPU):
+    every loss and every discriminator / council-discriminator gradient within 1e-3."""
+    cfg = _cfg("male2female_council_folder.yaml", 4)
+    errs = P.iteration_vs_oracle(cga, cfg, 256, 4, seed=1, report="cfg3 256^2 council 4 B4 (fp32 oracle only)", fp64=False)
+    assert "loss/disc_total" in errs and any(k[0] == "grad" and k[1] == "disc" for k in errs if not isinstance(k, str))
+
+
 def test_cfg2_iteration_vs_oracle(cga):
     """BASELINE.json configs[1]: glasses 128x128, council 1 -- one generator / discriminator pair, no council step."""
     cfg = _cfg("glasses_council_folder.yaml", 1)

@@ -42,6 +42,7 @@ def oracle_taps(sd, hp, x, s, dtype):
 
 
 def ours_taps(tr, gen, x, s):
+    cga.ops.NORM_NO_F32 = False      # the hooks below read every block's fp32 output
     taps, hooks = [], []
     for m in list(gen.enc_content.modules()) + list(gen.dec.modules()):
         if isinstance(m, N.Conv2dBlock):
