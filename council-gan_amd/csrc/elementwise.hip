@@ -480,6 +480,19 @@ extern "C" int cg_fill(float* p, size_t n, float value, cg_stream_t stream) {
     if (n == 0) return CG_OK;
     EW_LAUNCH(fill_kernel, n, p, n, value);
 }
+// {hi, lo} planes -> fp32 (hi + lo, divided by the device-side scale when there is one): the way back for the rare consumer that
+// reads fp32 from a tensor its producer emitted in split form only (layer widths the split-precision weight gradient does not take)
+__global__ __launch_bounds__(256) void unsplit_f16_kernel(const _Float16* __restrict__ zs, size_t lo_elems, const float* __restrict__ scale_dev,
+                                                          float* __restrict__ out, size_t n) {
+    const float inv = scale_dev ? 1.f / scale_dev[0] : 1.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = ((float)zs[cg_il(i)] + (float)zs[lo_elems + cg_il(i)]) * inv;
+}
+extern "C" int cg_unsplit_f16(const void* z_split, size_t lo_elems, const float* scale_dev, float* out, size_t n, cg_stream_t stream) {
+    CG_CHECK_ARG(z_split && out, "cg_unsplit_f16: null pointer");
+    if (n == 0) return CG_OK;
+    EW_LAUNCH(unsplit_f16_kernel, n, (const _Float16*)z_split, lo_elems, scale_dev, out, n);
+}
 extern "C" int cg_add(const float* a, const float* b, float* out, size_t n, cg_stream_t stream) {
     CG_CHECK_ARG(a && b && out, "cg_add: null pointer");
     if (n == 0) return CG_OK;

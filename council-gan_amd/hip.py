@@ -35,7 +35,7 @@ class Tuning(ctypes.Structure):
     """cg_tuning: the library's kernel-selection table (its only process-wide state)."""
     _fields_ = [(n, c_int32) for n in ("fwd_thin", "wgrad_thin", "wgrad_x3_bm256", "wgrad_x3_wide", "wgrad_x3_perm",
                                        "wgrad_legacy", "x3_wide", "x3_thin_out", "x3_korder", "tile_rows_scale",
-                                       "no_amax_atomic", "wgrad_x3_multitap")] + [("reserved", c_int32 * 4)]
+                                       "no_amax_atomic", "wgrad_x3_multitap", "x3_cls_minor")] + [("reserved", c_int32 * 3)]
 
 
 class HipLibraryMissing(RuntimeError):
@@ -63,6 +63,7 @@ _SIGS = {
     "cg_conv2d_dgrad_x3_prep": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
     "cg_conv2d_dgrad_x3_run": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_float, _P, c_int, c_int, _P, _P,
                                        POINTER(c_int), _P]),
+    "cg_unsplit_f16": (c_int, [_P, c_size_t, _P, _P, c_size_t, _P]),
     "cg_upconv_wt_elems": (c_size_t, [c_int, c_int]),
     "cg_upconv_prep_x3": (c_int, [POINTER(Group), _P, c_int, c_int, c_float, _P, _P, _P, _P]),
     "cg_upconv2d_fwd_x3": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_float, _P, _P, _P, _P, c_size_t,

@@ -309,6 +309,19 @@ class Decoder_V2_atten(nn.Module):
             i += 3
         return blocks
 
+    def prepare_split_weights(self):
+        """Fill the per-weight-version caches the tape-free trunk reads (the summed-tap weights of the upsampling layers,
+        ops.SplitWeights.upconv_weights) on the CURRENT stream -- Council_Trainer calls it before its side streams fork."""
+        i = 1
+        for _ in range(self.n_upsample):
+            blk = self.model[i + 1]
+            wmgr = getattr(blk, '_cg_wmgr', None)
+            w = blk.conv.weight
+            if wmgr is not None and ops.UPCONV and ops.X3_FORWARD and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 \
+                    and getattr(w, '_cg_grad', None) is not None and tuple(w.shape[2:]) == (3, 3):
+                wmgr.upconv_weights(w, ops._grp(w), ops.group_n())
+            i += 3
+
     def _trunk_split(self, x, want_f32=True):
         """ResBlocks + upsampling convs on the split-precision path (tape-free passes only):
         every 3x3 conv reads {hi, lo} fp16 planes written by the AdaIN apply before it."""

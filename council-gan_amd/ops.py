@@ -255,7 +255,11 @@ class _Conv2d(torch.autograd.Function):
         x3_wgrad = X3_BACKWARD and need_dw and ctx.xsplit is not None and bool(lib.cg_conv2d_wgrad_x3_ok_g(byref(g), grp))
         fp32_needed = (need_dx and not x3_dgrad) or (need_dw and not x3_wgrad)
         if ctx.x_no_f32 and need_dw and not x3_wgrad:
-            raise hip.HipError("the weight gradient of this layer reads its input in fp32, but the input exists in split form only")
+            # this width takes the fp32 weight gradient, but the producer wrote the {hi, lo} planes only: rebuild the values
+            # (22 significand bits -- what the split-precision kernel would have multiplied)
+            xs = ctx.xsplit
+            x = torch.empty_like(x)
+            check(lib.cg_unsplit_f16(xs.hi_ptr(), xs.lo, xs.scale_ptr(), ptr(x), x.numel(), stream()), "cg_unsplit_f16")
         dzs = None
         if act:
             if x3_dgrad or x3_wgrad:
@@ -536,7 +540,7 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=
     # one's epilogue measure them (stats is None: no instance norm in between)
     amax_out = [] if (X3_FORWARD and X3_DYNAMIC_INPUT and stats is None and out_split is None and weight.dim() == 4 and
                       weight.shape[0] % 32 == 0) else None
-    if no_f32 and (xsplit is None or wsplit is None or x.requires_grad and not X3_BACKWARD):
+    if no_f32 and (xsplit is None or wsplit is None):
         raise hip.HipError("an activation produced in split form only reached a convolution that reads fp32")
     dz_ok = [] if (stats is not None and X3_BACKWARD and xsplit is not None) else None      # a norm follows
     y = _Conv2d.apply(x, x2, weight, bias, getattr(weight, "_cg_grad", None),

@@ -468,6 +468,13 @@ class Council_Trainer(nn.Module):
                         self._content(d, grp, xr, need_grad=False)
             if self._split_fwd:
                 self._pools['gen'].split.refresh()
+                # the generators' summed-tap upsample-convolution weights are prepared once per weight version and cached: do it
+                # HERE, before the fork -- both side streams decode with them, and a cache entry filled on one side stream
+                # would be read by the other without an ordering between the two
+                for grp in groups:
+                    for d in self._dirs:
+                        with ops.members(len(grp)):
+                            self._nets('gen', d)[grp[0]].dec.prepare_split_weights()
             ev = torch.cuda.Event()
             ev.record(main)
             self._e0 = (ev, key)

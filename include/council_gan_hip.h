@@ -187,6 +187,8 @@ int cg_conv2d_dgrad_x3_run(const cg_conv_geom* g, const cg_group* group, const v
  *                        dw at group->stride).
  *   cg_colsum_split:     db[c] (+)= sum over rows of a {hi, lo} tensor [rows_total][C] / *scale_dev -- the bias gradient of a layer
  *                        whose dz exists in split form only (rows_total = all members' rows, member-major). */
+/* {hi, lo} planes -> fp32: out[i] = (hi[i] + lo[i]) / *scale_dev (scale_dev NULL = 1) in the tensor's physical element order */
+int cg_unsplit_f16(const void* z_split, size_t lo_elems, const float* scale_dev, float* out, size_t n, cg_stream_t stream);
 size_t cg_upconv_wt_elems(int Cout, int Cin);
 int cg_upconv_prep_x3(const cg_group* group, const float* w, int Cout, int Cin, float w_scale, const float* w_scale_dev,
                       void* wt_fwd, void* wt_bwd, cg_stream_t stream);
@@ -262,7 +264,9 @@ typedef struct cg_tuning {
                               * batch-1 parity run exercises the tiles the batch-k benchmark selects */
     int32_t no_amax_atomic;  /* CG_NO_AMAX_ATOMIC (0): launches with > 1024 blocks do not report output maxima */
     int32_t wgrad_x3_multitap; /* CG_WGRAD_X3_MULTITAP (1): 128-wide K-tiles spanning several taps for 32 / 64 input channels */
-    int32_t reserved[4];
+    int32_t x3_cls_minor;    /* CG_X3_CLS_MINOR (1): multi-class launches (strided data gradients, upsample-convolutions) order their blocks
+                              * class-minor, so that the output-parity classes of one row tile share an XCD's L2 */
+    int32_t reserved[3];
 } cg_tuning;
 int cg_tuning_get(cg_tuning* out);
 int cg_tuning_set(const cg_tuning* in);

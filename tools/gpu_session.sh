@@ -29,13 +29,13 @@ for st in "$@"; do
     tests_all) pt ${n}_all 900 tests -m gpu ;;
     tests_k) pt ${n}_k 300 tests -m gpu -s -k "$arg" ;;
     bench)  # bench[:comma-separated extra args]
-      timeout -k 5 240 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-exact-fp32 --shape-report $O/${n}_shapes.txt ${arg//,/ } < /dev/null > $O/${n}_bench.json 2> $O/${n}_bench.err
+      timeout -k 5 240 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-exact-fp32 --no-other-configs --shape-report $O/${n}_shapes.txt ${arg//,/ } < /dev/null > $O/${n}_bench.json 2> $O/${n}_bench.err
       echo "[bench ${arg}] $(grep -o "$J" $O/${n}_bench.json) t=$(el)" ;;
     bench_full)  # the driver's command: every leg (exact fp32, cpu baseline)
       timeout -k 5 400 python bench.py --steps 20 --warmup 5 ${arg//,/ } < /dev/null > $O/${n}_bench_full.json 2> $O/${n}_bench_full.err
       echo "[bench_full ${arg}] $(grep -o "$J" $O/${n}_bench_full.json) t=$(el)" ;;
     prof)  # rocprofv3 --kernel-trace --stats of the default bench command (tools/prof_bench.sh)
-      STEPS=5 BENCH_ARGS="--no-exact-fp32 ${arg//,/ }" timeout -k 5 240 bash tools/prof_bench.sh ${O#gpurun_out/}/${n}_prof < /dev/null > $O/${n}_prof.log 2>&1
+      STEPS=5 BENCH_ARGS="--no-exact-fp32 --no-other-configs ${arg//,/ }" timeout -k 5 240 bash tools/prof_bench.sh ${O#gpurun_out/}/${n}_prof < /dev/null > $O/${n}_prof.log 2>&1
       echo "[prof] $(grep -o "$J" $O/${n}_prof/bench.json) t=$(el)" ;;
     ab_x3)  # ab_x3:<cfgs>[:reps]   (EXTRA_SHAPES from the environment)
       cfgs=${arg%%:*}

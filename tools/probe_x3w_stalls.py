@@ -33,7 +33,7 @@ for cfg in (16, PCFG):
     e1.synchronize()
     print("cfg %d: %.1f us per launch" % (cfg, e0.elapsed_time(e1) * 100))
 tiles = N * 64 * 64 // 256
-nw = min(4096, tiles * 8)
+nw = min(2048, tiles * 8)
 buf = (ctypes.c_longlong * (nw * 16))()
 hip.check(lib.cg_debug_fetch(buf, nw * 16), "cg_debug_fetch")
 d = np.frombuffer(buf, dtype=np.int64).reshape(nw, 16)
@@ -46,3 +46,17 @@ for name, sel in (("all", d[:, 5] >= 0), ("early 0-3", d[:, 5] < 4), ("late 4-7"
     ghz = (r[:, 0] / (r[:, 6] * 10.0)).mean()      # cycles per ns
     print("%-10s %10.0f %10.0f %10.0f %10.0f %10.0f %8.2f" % (name, tot, vm, bar, dma, tot - vm - bar - dma, ghz))
 print("(cycles per K slice and wave; 'rest' = the four MFMA steps with their fragment reads; loop/slice x %d slices / clock = kernel time)" % nk)
+
+# one slice (kt = nk / 2) of one block, wave by wave: absolute shader-clock stamps relative to the block's earliest stamp
+full = (ctypes.c_longlong * (4096 * 16))()
+hip.check(lib.cg_debug_fetch(full, 4096 * 16), "cg_debug_fetch")
+t = np.frombuffer(full, dtype=np.int64).reshape(4096, 16)[2048:]
+names = ["slice top", "step0 issued", "step1 issued", "step2 issued", "step3 issued", "before dma-landed wait", "after wait",
+         "after barrier", "after early DMA", "late DMA start", "late DMA end"]
+for blk in (0, 100):
+    w = t[blk * 8:(blk + 1) * 8, :11].astype(np.float64)
+    base = w[w > 0].min()
+    print("block %d (waves 0-3 issue their DMA behind the barrier, waves 4-7 at the next slice's step 0; SIMD = wave %% 4)" % blk)
+    print("%-24s" % "event" + " ".join("%8s" % ("w%d" % i) for i in range(8)))
+    for k, nmk in enumerate(names):
+        print("%-24s" % nmk + " ".join("%8s" % ("%.0f" % (w[i, k] - base) if w[i, k] > 0 else "-") for i in range(8)))
