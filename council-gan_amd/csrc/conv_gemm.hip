@@ -1565,6 +1565,7 @@ struct FwdAmax {
 static thread_local FwdAmax fwd_amax;
 constexpr int CG_AMAX_SLOTS_MAX = 1024;     // == CG_AMAX_MAX_SLOTS of conv_x3.inc (state[2 .. 2 + 1024))
 __global__ __launch_bounds__(256) void zero_slots_kernel(float* __restrict__ slots) { slots[blockIdx.x * 256 + threadIdx.x] = 0.f; }
+__global__ void zero2_kernel(float* __restrict__ p) { if (threadIdx.x < 2) p[threadIdx.x] = 0.f; }
 // slots a launch of `blocks` blocks fills (block_amax_store): one each, or 1024 shared ones that must start at zero
 static int amax_slots_for(long blocks, float* state, hipStream_t st) {
     if (blocks <= CG_AMAX_SLOTS_MAX) return (int)blocks;
@@ -2070,17 +2071,43 @@ extern "C" int cg_split_f16(const float* x, void* out, size_t n, size_t lo_elems
     return CG_OK;
 }
 
+static int x3_epilogue_check(const cg_x3_epilogue* epi, const void* y_split, const float* amax_state, const char* who) {
+    if (!epi) return CG_OK;
+    CG_CHECK_ARG(CG_X3_INTERLEAVE, "%s: the bounded-split epilogue needs the interleaved operand layout", who);
+    CG_CHECK_ARG(!epi->l1_ctl || (y_split && epi->out_state && epi->in_state && epi->in_nslots >= 0 && epi->in_nslots <= CG_AMAX_MAX_SLOTS),
+                 "%s: bounded split needs the output planes, the input's state and an output state", who);
+    CG_CHECK_ARG(!epi->l1_ctl || amax_state == nullptr || amax_state == epi->out_state,
+                 "%s: the block maxima of a bounded-split output go to its own state (amax_state == out_state)", who);
+    CG_CHECK_ARG(!epi->act_src || epi->act_type == CG_ACT_RELU || epi->act_type == CG_ACT_LRELU,
+                 "%s: the fused activation backward takes relu / lrelu (sign-only derivatives)", who);
+    return CG_OK;
+}
+static X3Epi x3_epilogue_of(const cg_x3_epilogue* epi) {
+    X3Epi e;
+    if (epi) {
+        e.ctl = epi->l1_ctl;
+        e.in_state = epi->in_state;
+        e.in_nslots = epi->in_nslots;
+        e.act_type = epi->act_src ? epi->act_type : 0;
+        e.act_src = (const _Float16*)epi->act_src;
+        e.out_state = epi->l1_ctl ? epi->out_state : nullptr;
+    }
+    return e;
+}
+
 static int conv2d_fwd_x3_impl(const cg_conv_geom* g, const cg_group* group, const void* xs, size_t x_lo_elems, const void* ws,
                               size_t w_lo_elems, float w_scale, const float* w_scale_dev, const float* x_scale_dev,
                               const float* bias, float* y, void* y_split, size_t y_lo_elems, double* stats,
                               size_t stats_bytes, int* rows_per_partial, int tile_cfg, float* amax_state, int* amax_nslots,
-                              cg_stream_t stream, const char* who) {
+                              cg_stream_t stream, const char* who, const cg_x3_epilogue* epi = nullptr) {
     int rc = validate_geom(g, who);
     CG_CHECK_ARG((amax_state == nullptr) == (amax_nslots == nullptr), "%s: amax_state and amax_nslots go together", who);
     if (amax_nslots) *amax_nslots = 0;
     if (rows_per_partial) *rows_per_partial = 0;
     if (rc) return rc;
-    CG_CHECK_ARG(xs && ws && y && w_scale > 0.f, "%s: null pointer / bad scale", who);
+    CG_CHECK_ARG(xs && ws && (y || (y_split && epi)) && w_scale > 0.f, "%s: null pointer / bad scale", who);
+    rc = x3_epilogue_check(epi, y_split, amax_state, who);
+    if (rc) return rc;
     Grp gr;
     rc = grp_from(group, g->N, gr, who);
     if (rc) return rc;
@@ -2112,6 +2139,7 @@ static int conv2d_fwd_x3_impl(const cg_conv_geom* g, const cg_group* group, cons
     X3Extra ex;
     ex.w_scale_dev = w_scale_dev;
     ex.mb = Members{gr.n, 0, gr.stride * 4, gr.stride * 4};       // interleaved {hi, lo}: 4 bytes per element
+    ex.epi = x3_epilogue_of(epi);
     fwd_amax.state = amax_state;
     fwd_amax.nslots = 0;
     rc = launch_x3_cfg(cfg, b, 1, xs, bias, y, (unsigned)(x_lo_elems * 2), (unsigned)x_span, 1.0f / w_scale, x_scale_dev, st,
@@ -2142,6 +2170,97 @@ extern "C" int cg_conv2d_fwd_x3_g(const cg_conv_geom* g, const cg_group* group, 
     return conv2d_fwd_x3_impl(g, group, xs, x_lo_elems, ws, w_lo_elems, w_scale, w_scale_dev, x_scale_dev, bias, y, y_split,
                               y_lo_elems, stats, stats_bytes, rows_per_partial, tile_cfg, amax_state, amax_nslots, stream,
                               "cg_conv2d_fwd_x3_g");
+}
+
+// cg_conv2d_fwd_x3_g with the bounded-split epilogue (include/council_gan_hip.h, cg_x3_epilogue): y may be NULL (planes only)
+extern "C" int cg_conv2d_fwd_x3_e(const cg_conv_geom* g, const cg_group* group, const void* xs, size_t x_lo_elems,
+                                  const void* ws, size_t w_lo_elems, float w_scale, const float* w_scale_dev,
+                                  const float* x_scale_dev, const float* bias, float* y, void* y_split, size_t y_lo_elems,
+                                  const cg_x3_epilogue* epi, int tile_cfg, int* amax_nslots, cg_stream_t stream) {
+    CG_CHECK_ARG(epi && amax_nslots, "cg_conv2d_fwd_x3_e: the epilogue descriptor and amax_nslots are required");
+    return conv2d_fwd_x3_impl(g, group, xs, x_lo_elems, ws, w_lo_elems, w_scale, w_scale_dev, x_scale_dev, bias, y, y_split,
+                              y_lo_elems, nullptr, 0, nullptr, tile_cfg, epi->out_state, amax_nslots, stream,
+                              "cg_conv2d_fwd_x3_e", epi);
+}
+
+// {largest row (by_input_channel = 0: over output channels of sum_{t,ci} |w|) or column (1: over input channels of
+// sum_{co,t} |w|) 1-norm of a convolution weight [Cout][T][Cin], largest |bias|}, the maximum over the members of the group
+namespace {
+__global__ __launch_bounds__(256) void weight_l1_rows_kernel(const float* __restrict__ w, const float* __restrict__ bias, int K,
+                                                             long long w_mstride, long long b_mstride, unsigned* __restrict__ out_bits) {
+    // one block per (output row, member): sum_k |w[row][k]|; positive floats order like their bit patterns -> integer atomic max
+    const int member = blockIdx.y, row = blockIdx.x;
+    const float* r = w + (long long)member * w_mstride + (size_t)row * K;
+    __shared__ float red[4];
+    float a = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) a += fabsf(r[k]);
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(out_bits, __float_as_uint(red[0] + red[1] + red[2] + red[3]));
+        if (bias) atomicMax(out_bits + 1, __float_as_uint(fabsf(bias[(long long)member * b_mstride + row])));
+    }
+}
+constexpr int L1_CHUNKS = 32;
+// column sums in two deterministic stages: (32 channels x 8 row lanes) per block over one chunk of the Cout * T rows -> partial
+// [member][chunk][ci]; then per channel the chunks are added in order and the maximum taken
+__global__ __launch_bounds__(256) void weight_l1_cols_partial(const float* __restrict__ w, int R, int Cin, long long w_mstride,
+                                                              float* __restrict__ part) {
+    const int member = blockIdx.z, chunk = blockIdx.y;
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+    const int per = (R + L1_CHUNKS - 1) / L1_CHUNKS, r0 = chunk * per, r1 = min(R, r0 + per);
+    const float* wm = w + (long long)member * w_mstride;
+    float a = 0.f;
+    if (c < Cin)
+        for (int r = r0 + rl; r < r1; r += 8) a += fabsf(wm[(size_t)r * Cin + c]);
+    __shared__ float red[8][33];
+    red[rl][threadIdx.x & 31] = a;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < Cin) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+        part[((size_t)member * L1_CHUNKS + chunk) * Cin + c] = t;
+    }
+}
+__global__ __launch_bounds__(256) void weight_l1_cols_final(const float* __restrict__ part, int Cin, int nmember, float* __restrict__ out2) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < Cin * nmember; i += 256) {
+        const int member = i / Cin, c = i - member * Cin;
+        float t = 0.f;
+        for (int k = 0; k < L1_CHUNKS; ++k) t += part[((size_t)member * L1_CHUNKS + k) * Cin + c];
+        m = fmaxf(m, t);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out2[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        out2[1] = 0.f;
+    }
+}
+}  // namespace
+extern "C" size_t cg_weight_l1_workspace(int Cin, int nmember) { return (size_t)(nmember < 1 ? 1 : nmember) * L1_CHUNKS * Cin * sizeof(float); }
+extern "C" int cg_weight_l1_bound(const cg_group* group, const float* w, int Cout, int T, int Cin, const float* bias,
+                                  int by_input_channel, float* out2, void* ws, size_t ws_bytes, cg_stream_t stream) {
+    CG_CHECK_ARG(w && out2 && Cout > 0 && T > 0 && Cin > 0, "cg_weight_l1_bound: bad args");
+    const int n = group ? group->n : 1;
+    const long long ms = group ? group->stride : 0;
+    hipStream_t st = cg_s(stream);
+    if (!by_input_channel) {
+        hipLaunchKernelGGL(zero2_kernel, dim3(1), dim3(64), 0, st, out2);
+        hipLaunchKernelGGL(weight_l1_rows_kernel, dim3(Cout, n), dim3(256), 0, st, w, bias, T * Cin, ms, ms,
+                           reinterpret_cast<unsigned*>(out2));
+    } else {
+        if (!ws || ws_bytes < cg_weight_l1_workspace(Cin, n)) return cg_set_error(CG_ERR_WORKSPACE, "cg_weight_l1_bound: workspace too small");
+        hipLaunchKernelGGL(weight_l1_cols_partial, dim3((Cin + 31) / 32, L1_CHUNKS, n), dim3(256), 0, st, w, Cout * T, Cin, ms, (float*)ws);
+        hipLaunchKernelGGL(weight_l1_cols_final, dim3(1), dim3(256), 0, st, (const float*)ws, Cin, n, out2);
+    }
+    CG_LAUNCH_CHECK("weight_l1_kernel");
+    return CG_OK;
 }
 
 extern "C" int cg_split_f16_dynamic(const float* x, void* out, size_t n, size_t lo_elems, float* state, int nslots,
@@ -2638,16 +2757,20 @@ extern "C" int cg_conv2d_dgrad_x3_prep(const cg_conv_geom* g, const cg_group* gr
                             (unsigned)wt_lo, gr.n, gr.stride, (long long)p.ws_floats, w_scale_dev);
 }
 
-extern "C" int cg_conv2d_dgrad_x3_run(const cg_conv_geom* g, const cg_group* group, const void* dz_split, size_t dz_lo_elems,
-                                      const float* dz_scale_dev, const void* wt, float w_scale, const float* w_scale_dev,
-                                      int ci0, int nci, float* dx, float* amax_state, int* amax_nslots, cg_stream_t stream) {
+static int conv2d_dgrad_x3_run_impl(const cg_conv_geom* g, const cg_group* group, const void* dz_split, size_t dz_lo_elems,
+                                    const float* dz_scale_dev, const void* wt, float w_scale, const float* w_scale_dev,
+                                    int ci0, int nci, float* dx, void* dx_split, size_t dx_lo_elems, const cg_x3_epilogue* epi,
+                                    float* amax_state, int* amax_nslots, cg_stream_t stream) {
     static thread_local DgradPlan p;
     Grp gr;
     CG_CHECK_ARG((amax_state == nullptr) == (amax_nslots == nullptr), "cg_conv2d_dgrad_x3_run: amax_state and amax_nslots go together");
     if (amax_nslots) *amax_nslots = 0;
     int rc = dgrad_x3_checks(g, group, ci0, nci, gr, p, "cg_conv2d_dgrad_x3_run");
     if (rc) return rc;
-    CG_CHECK_ARG(dz_split && wt && dx && dz_scale_dev && w_scale > 0.f, "cg_conv2d_dgrad_x3_run: null pointer / bad scale");
+    CG_CHECK_ARG(dz_split && wt && (dx || (dx_split && epi)) && dz_scale_dev && w_scale > 0.f, "cg_conv2d_dgrad_x3_run: null pointer / bad scale");
+    rc = x3_epilogue_check(epi, dx_split, amax_state, "cg_conv2d_dgrad_x3_run");
+    if (rc) return rc;
+    CG_CHECK_ARG(!dx_split || x3_lo_ok(dx_lo_elems, (size_t)g->N * (g->H << g->up) * (g->W << g->up) * nci * 2), "cg_conv2d_dgrad_x3_run: bad dx lo offset");
     const size_t wt_elems = p.ws_floats;          // one fp16 plane = as many elements as the fp32 layout had floats
     const size_t dz_plane = (size_t)g->N * g->Ho * g->Wo * g->Cout * 2;
     CG_CHECK_ARG(x3_lo_ok(dz_lo_elems, dz_plane) && x3_span(dz_lo_elems, dz_plane) < (size_t)CG_OOB,
@@ -2669,13 +2792,31 @@ extern "C" int cg_conv2d_dgrad_x3_run(const cg_conv_geom* g, const cg_group* gro
     fwd_amax.state = amax_state;
     fwd_amax.nslots = 0;
     fwd_amax.all_classes = true;
+    ex.epi = x3_epilogue_of(epi);
     rc = launch_x3_cfg(pick_x3_cfg(nci, m_total, g->Cout, p.cg[0].T), b, p.ncls, dz_split, nullptr, dx, (unsigned)(dz_lo_elems * 2),
-                       (unsigned)x3_span(dz_lo_elems, dz_plane), 1.0f / w_scale, dz_scale_dev, cg_s(stream), nullptr, nullptr, 0,
-                       ex);
+                       (unsigned)x3_span(dz_lo_elems, dz_plane), 1.0f / w_scale, dz_scale_dev, cg_s(stream), nullptr, dx_split,
+                       dx_lo_elems, ex);
     if (amax_nslots && !rc) *amax_nslots = fwd_amax.nslots;
     fwd_amax.state = nullptr;
     fwd_amax.all_classes = false;
     return rc;
+}
+
+extern "C" int cg_conv2d_dgrad_x3_run(const cg_conv_geom* g, const cg_group* group, const void* dz_split, size_t dz_lo_elems,
+                                      const float* dz_scale_dev, const void* wt, float w_scale, const float* w_scale_dev,
+                                      int ci0, int nci, float* dx, float* amax_state, int* amax_nslots, cg_stream_t stream) {
+    return conv2d_dgrad_x3_run_impl(g, group, dz_split, dz_lo_elems, dz_scale_dev, wt, w_scale, w_scale_dev, ci0, nci, dx, nullptr, 0,
+                                    nullptr, amax_state, amax_nslots, stream);
+}
+// ... with the epilogue extras: dx as {hi, lo} planes on an a-priori scale (dx itself may then be NULL) and / or multiplied by
+// the activation derivative of the layer below (cg_x3_epilogue)
+extern "C" int cg_conv2d_dgrad_x3_run_e(const cg_conv_geom* g, const cg_group* group, const void* dz_split, size_t dz_lo_elems,
+                                        const float* dz_scale_dev, const void* wt, float w_scale, const float* w_scale_dev,
+                                        int ci0, int nci, float* dx, void* dx_split, size_t dx_lo_elems, const cg_x3_epilogue* epi,
+                                        float* amax_state, int* amax_nslots, cg_stream_t stream) {
+    CG_CHECK_ARG(epi, "cg_conv2d_dgrad_x3_run_e: the epilogue descriptor is required");
+    return conv2d_dgrad_x3_run_impl(g, group, dz_split, dz_lo_elems, dz_scale_dev, wt, w_scale, w_scale_dev, ci0, nci, dx, dx_split,
+                                    dx_lo_elems, epi, amax_state, amax_nslots, stream);
 }
 
 extern "C" int cg_conv2d_dgrad_x3(const cg_conv_geom* g, const void* dz_split, size_t dz_lo_elems,

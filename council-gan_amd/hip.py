@@ -31,6 +31,12 @@ class Group(ctypes.Structure):
     _fields_ = [("n", c_int32), ("reserved", c_int32), ("stride", c_int64)]
 
 
+class X3Epilogue(ctypes.Structure):
+    """cg_x3_epilogue: bounded-split / fused activation-backward extras of the split-precision forward and data-gradient calls."""
+    _fields_ = [("l1_ctl", c_void_p), ("in_state", c_void_p), ("in_nslots", c_int32), ("act_type", c_int32),
+                ("act_src", c_void_p), ("out_state", c_void_p)]
+
+
 class Tuning(ctypes.Structure):
     """cg_tuning: the library's kernel-selection table (its only process-wide state)."""
     _fields_ = [(n, c_int32) for n in ("fwd_thin", "wgrad_thin", "wgrad_x3_bm256", "wgrad_x3_wide", "wgrad_x3_perm",
@@ -63,6 +69,12 @@ _SIGS = {
     "cg_conv2d_dgrad_x3_prep": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
     "cg_conv2d_dgrad_x3_run": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_float, _P, c_int, c_int, _P, _P,
                                        POINTER(c_int), _P]),
+    "cg_weight_l1_workspace": (c_size_t, [c_int, c_int]),
+    "cg_weight_l1_bound": (c_int, [POINTER(Group), _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_size_t, _P]),
+    "cg_conv2d_fwd_x3_e": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, c_size_t, c_float, _P, _P, _P, _P, _P,
+                                   c_size_t, POINTER(X3Epilogue), c_int, POINTER(c_int), _P]),
+    "cg_conv2d_dgrad_x3_run_e": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_float, _P, c_int, c_int, _P, _P,
+                                         c_size_t, POINTER(X3Epilogue), _P, POINTER(c_int), _P]),
     "cg_unsplit_f16": (c_int, [_P, c_size_t, _P, _P, c_size_t, _P]),
     "cg_upconv_wt_elems": (c_size_t, [c_int, c_int]),
     "cg_upconv_prep_x3": (c_int, [POINTER(Group), _P, c_int, c_int, c_float, _P, _P, _P, _P]),

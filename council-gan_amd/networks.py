@@ -116,7 +116,8 @@ class Conv2dBlock(nn.Module):
         wmgr = getattr(self, '_cg_wmgr', None)
         want_split = wmgr is not None and self.conv.out_channels % 32 == 0
         y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, fused_act, x2=x2,
-                       upsample=upsample, stats=stats, wmgr=wmgr, want_split=want_split)
+                       upsample=upsample, stats=stats, wmgr=wmgr, want_split=want_split,
+                       want_f32=want_f32 or self.norm is not None)
         if self.norm_type == 'in':
             y = ops.instance_norm(y, act=act, residual=residual, eps=self.norm.eps, stats=stats, want_split=want_split,
                                   want_f32=want_f32)
@@ -504,7 +505,7 @@ class MsImageDis(nn.Module):
         for si, model in enumerate(self.cnns):
             y = x
             for blk in list(model)[:-1]:
-                y = blk(y)
+                y = blk(y, want_f32=False)           # every block's output is read by the next convolution only
             last = model[len(model) - 1]
             outputs.append(ops.conv2d(y, last.weight, last.bias, 1, 0, 'none', wmgr=getattr(self, '_cg_wmgr', None)))
             if si + 1 < len(self.cnns):
@@ -570,9 +571,9 @@ class MsImageDisCouncil(nn.Module):
         outputs = []
         for si, model in enumerate(self.cnns):
             blocks = list(model)
-            y = blocks[0](x, x2=x_input)
+            y = blocks[0](x, x2=x_input, want_f32=False)      # every block's output is read by the next convolution only
             for blk in blocks[1:-2]:
-                y = blk(y)
+                y = blk(y, want_f32=False)
             wmgr = getattr(self, '_cg_wmgr', None)
             y = ops.conv2d(y, blocks[-2].weight, blocks[-2].bias, 1, 0, 'none', wmgr=wmgr, want_split=wmgr is not None)
             outputs.append(ops.conv2d(y, blocks[-1].weight, blocks[-1].bias, 1, 0, 'none', wmgr=wmgr))

@@ -167,7 +167,8 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x2, weight, bias, wgrad_buf, bgrad_buf, stride, pad, act, up, stats, xsplit=None, wsplit=None,
-                out_split=None, amax_out=None, wmgr=None, wref=None, dz_split_ok=None, x_no_f32=False):
+                out_split=None, amax_out=None, wmgr=None, wref=None, dz_split_ok=None, x_no_f32=False, bounded=None, x_bwd=None,
+                bwd_want=None, want_f32=True):
         # wref = (cg_group or None, the Parameter object): resolved by the caller, where the tensor still carries its
         # Python attributes
         lib = _lib()
@@ -194,16 +195,37 @@ class _Conv2d(torch.autograd.Function):
         if xsplit is not None and wsplit is not None and x3_eligible(C1, C2):
             # split-precision forward (fp16 x 3 MFMA, 22 significand bits)
             ysp = None
-            if out_split is not None:
-                ysp = SplitTensor(torch.empty(2 * y.numel(), dtype=torch.float16, device=y.device), y.shape)
+            if bounded is not None:
+                # bounded split (include/council_gan_hip.h, cg_x3_epilogue): the epilogue writes the {hi, lo} planes of this
+                # un-normalised output on an a-priori scale -- the next convolution reads them, nobody measures + splits y.
+                # With a sign-only activation (relu / lrelu) nothing reads y in fp32 any more (the backward takes the sign from
+                # the hi plane): the fp32 copy is not written, `y` stays an uninitialised carrier for the autograd graph
+                skip_f32 = BOUNDED_NO_F32 and not want_f32 and act in (ACT["relu"], ACT["lrelu"])
+                ostate = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=y.device)
+                buf = torch.empty(2 * y.numel(), dtype=torch.float16, device=y.device)
+                epi = hip.X3Epilogue(bounded.data_ptr(), xsplit.state.data_ptr(), int(xsplit.nslots), 0, None, ostate.data_ptr())
+                ns = ctypes.c_int(0)
+                check(lib.cg_conv2d_fwd_x3_e(byref(g), grp, xsplit.hi_ptr(), xsplit.lo, wsplit.hi_ptr(), wsplit.lo,
+                                             float(wsplit.scale), wsplit.scale_ptr(), xsplit.scale_ptr(), ptr(bias),
+                                             None if skip_f32 else ptr(y), ptr(buf), x3_lo(y.numel()), byref(epi), -1, byref(ns),
+                                             stream()), "cg_conv2d_fwd_x3_e")
+                ysp = SplitTensor(buf, y.shape, state=ostate, nslots=ns.value)
                 out_split.append(ysp)
-            if amax_out is not None and ysp is None:     # the consumer will split y dynamically: hand it the block maxima
-                state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=y.device), ctypes.c_int(0)
-            check(lib.cg_conv2d_fwd_x3_g(byref(g), grp, xsplit.hi_ptr(), xsplit.lo, wsplit.hi_ptr(), wsplit.lo,
-                                         float(wsplit.scale), wsplit.scale_ptr(), xsplit.scale_ptr(), ptr(bias), ptr(y),
-                                         ysp.hi_ptr() if ysp else None, ysp.lo if ysp else 0, ptr(sws), sbytes, rp, -1,
-                                         ptr(state), byref(nslots) if nslots is not None else None, stream()),
-                  "cg_conv2d_fwd_x3")
+                if skip_f32:
+                    out_split.append(True)
+                if ns.value == 0:
+                    raise hip.HipError("bounded split: the kernel reported no output maxima")
+            else:
+                if out_split is not None:
+                    ysp = SplitTensor(torch.empty(2 * y.numel(), dtype=torch.float16, device=y.device), y.shape)
+                    out_split.append(ysp)
+                if amax_out is not None and ysp is None:     # the consumer will split y dynamically: hand it the block maxima
+                    state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=y.device), ctypes.c_int(0)
+                check(lib.cg_conv2d_fwd_x3_g(byref(g), grp, xsplit.hi_ptr(), xsplit.lo, wsplit.hi_ptr(), wsplit.lo,
+                                             float(wsplit.scale), wsplit.scale_ptr(), xsplit.scale_ptr(), ptr(bias), ptr(y),
+                                             ysp.hi_ptr() if ysp else None, ysp.lo if ysp else 0, ptr(sws), sbytes, rp, -1,
+                                             ptr(state), byref(nslots) if nslots is not None else None, stream()),
+                      "cg_conv2d_fwd_x3")
         else:
             if amax_out is not None and not want_stats:
                 state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=y.device), ctypes.c_int(0)
@@ -213,12 +235,26 @@ class _Conv2d(torch.autograd.Function):
             amax_out.append((state, nslots.value))
         if want_stats and rows.value:
             stats.append((sws, rows.value))
-        ctx.save_for_backward(x, x2, w, y if act else None)
+        y_no_f32 = bool(out_split is not None and len(out_split) > 1)
+        ctx.save_for_backward(x, x2, w, y if (act and not y_no_f32) else None)
+        ctx.ysplit = out_split[0] if y_no_f32 else None       # the activation backward takes the sign from its hi plane
         ctx.xsplit = xsplit if (xsplit is not None and wsplit is not None) else None     # reused by the x3 weight gradient
         ctx.x_no_f32 = bool(x_no_f32)
+        ctx.x_bwd = x_bwd        # what the producer of x wants from this layer's data gradient (see backward)
+        ctx.bwd_cell = None
         ctx.g, ctx.meta = g, (KH, KW, stride, pad, act, int(up), bias is not None)
         ctx.wgrad_buf, ctx.bgrad_buf = wgrad_buf, bgrad_buf
         ctx.grp, ctx.weight, ctx.wmgr, ctx.nm = grp, wparam, wmgr, _G.n      # backward may run outside the members() scope
+        if bwd_want is not None and act in (ACT["relu"], ACT["lrelu"]) and X3_BACKWARD and FUSED_ACT_BWD:
+            # This layer's activation backward can be folded into the data-gradient epilogue of the convolution that reads y
+            # (cg_x3_epilogue.act_src): tell it which forms of dz = dy * act'(y) this layer's own gradients will read
+            need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
+            need_dw = ctx.needs_input_grad[2] or (bias is not None and ctx.needs_input_grad[3])
+            dg = need_dx and g.Cout % 32 == 0 and g.stride <= 2 and (grp is None or (wmgr is not None and wparam is not None))
+            wg = need_dw and ctx.xsplit is not None and bool(lib.cg_conv2d_wgrad_x3_ok_g(byref(g), grp))
+            if need_dx or need_dw:
+                ctx.bwd_cell = [0]       # counts the consumers that folded this layer's activation backward into their data gradient
+                bwd_want.append((act, bool(dg or wg), bool((need_dx and not dg) or (need_dw and not wg)), ctx.bwd_cell))
         if dz_split_ok is not None and act == 0 and X3_BACKWARD:
             # Will BOTH gradients of this layer run on the split-precision kernels?  Then the norm behind it may hand its
             # dx over in split form only (cg_instnorm_bwd_split) -- the same conditions backward() evaluates.
@@ -261,7 +297,22 @@ class _Conv2d(torch.autograd.Function):
             x = torch.empty_like(x)
             check(lib.cg_unsplit_f16(xs.hi_ptr(), xs.lo, xs.scale_ptr(), ptr(x), x.numel(), stream()), "cg_unsplit_f16")
         dzs = None
-        if act:
+        applied = act and getattr(dy, "_cg_act_applied", None) == dy._version       # the consumer's data gradient already holds
+        if applied:                                                                 # dy * act'(y) in the forms this layer asked for
+            dz = dy
+            dzs = pre
+            if (dzs is None and (x3_dgrad or x3_wgrad)) or (fp32_needed and not getattr(dy, "_cg_has_f32", True)):
+                raise hip.HipError("a gradient with the activation backward folded in arrived without the form this layer reads")
+        elif act:
+            if ctx.bwd_cell is not None and ctx.bwd_cell[0]:
+                # a consumer multiplied its data gradient by act'(y) already, but what arrived here is not that tensor (several
+                # consumers' gradients were accumulated): applying act' again would square it
+                raise hip.HipError("fused activation backward: the output of this layer has more than one differentiated consumer "
+                                   "(set CG_FUSED_ACT_BWD=0)")
+            if y is None:       # y exists as {hi, lo} planes only (bounded split): rebuild it for the un-fused activation backward
+                ys = ctx.ysplit
+                y = torch.empty_like(dy)
+                check(lib.cg_unsplit_f16(ys.hi_ptr(), ys.lo, ys.scale_ptr(), ptr(y), y.numel(), stream()), "cg_unsplit_f16")
             if x3_dgrad or x3_wgrad:
                 dz, dzs = act_bwd_split(dy, y, act, fp32_needed, amax)  # no fp32 round trip of dz when nobody reads it
             else:
@@ -275,12 +326,14 @@ class _Conv2d(torch.autograd.Function):
                 dzs = pre
             elif x3_dgrad or x3_wgrad:
                 dzs = split_f16_dynamic(dz, amax)
-        if pre is not None and act:
+        if pre is not None and act and not applied:
             raise hip.HipError("a gradient delivered in split form only reached a layer with a fused activation")
         # data gradients: split-precision kernel when the layer qualifies (dz gets a device-side power-of-two scale)
         def dgrad(ci0, nci):
             if x3_dgrad:
-                return conv_dgrad_x3(g, dzs, w, ci0, nci, grp=grp, weight=ctx.weight, wmgr=ctx.wmgr, nm=ctx.nm)
+                fuse = ctx.x_bwd if (ci0 == 0 and nci == x.shape[1] and x2 is None and not up) else None
+                return conv_dgrad_x3(g, dzs, w, ci0, nci, grp=grp, weight=ctx.weight, wmgr=ctx.wmgr, nm=ctx.nm,
+                                     fuse=fuse, xsplit=ctx.xsplit)
             return conv_dgrad(g, dz, w, ci0, nci, grp=grp)
 
         def run_dgrads():
@@ -331,7 +384,7 @@ class _Conv2d(torch.autograd.Function):
                         t.record_stream(side)
         if not (side is not None and WGRAD_AFTER_DGRAD):
             dx, dx2 = run_dgrads()
-        return (dx, dx2, dw, db) + (None,) * 15
+        return (dx, dx2, dw, db) + (None,) * 19
 
 
 # Weight gradients leave the chain of dependent backward kernels: nothing downstream of a layer's backward needs its dW
@@ -495,19 +548,32 @@ def _upconv_ok(shape, weight, stride, pad, act, x2, wmgr):
     return ok
 
 
+# Bounded split / fused activation backward (include/council_gan_hip.h, cg_x3_epilogue) -- built, parity-tested
+# (tests/test_gpu_ops.py::test_bounded_split_chain_and_fused_activation_backward) and OFF by default: on the benchmark they remove
+# 5.7 ms of bandwidth passes per step (28 -> 10-12 bytes per element at every discriminator layer boundary), but the
+# convolution epilogues that take the work over are slower by as much, and the passes had been hiding under the sibling
+# update's convolutions (two side streams): 60.7 vs 60.5 ms per step on one GPU, 21.8 vs 21.4 ms on a one-member rank
+# (profiles/r04_bounded_split.txt).
+#   CG_BOUNDED_SPLIT=1: un-normalised conv outputs leave their kernel as {hi, lo} planes on an a-priori scale
+#   CG_BOUNDED_NO_F32=0: ... and are written in fp32 as well
+#   CG_FUSED_ACT_BWD=1: a layer's activation backward is folded into the data-gradient epilogue of its consumer
+BOUNDED_NO_F32 = os.environ.get("CG_BOUNDED_NO_F32", "1") != "0"
+FUSED_ACT_BWD = os.environ.get("CG_FUSED_ACT_BWD", "0") != "0"
+BOUNDED_SPLIT = os.environ.get("CG_BOUNDED_SPLIT", "0") != "0"
 X3_FORWARD = True     # module switches (Council_Trainer sets them from the config): split-precision forward convolutions,
 X3_BACKWARD = True    # split-precision data gradients, dynamic (device-scaled) splitting of un-normalised conv inputs
 X3_DYNAMIC_INPUT = True
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=False, stats=None, wmgr=None,
-           want_split=False):
+           want_split=False, want_f32=True):
     """Functional conv.  `weight` may be an nn.Parameter managed by a flat optimizer buffer.  `stats`: an empty
     list when an instance norm consumes the output next -- the conv appends (partials, rows) if its epilogue
     produced the norm's partial sums (pass the same list to instance_norm / adain).
     `wmgr` (SplitWeights): run the FORWARD on the split-precision kernel when the layer qualifies; the input's
     split form travels as the `_cg_split` attribute of `x` (set by the op that produced it), and with `want_split`
-    the output gets one for the next convolution."""
+    the output gets one for the next convolution.  `want_f32=False`: the caller knows that ONLY a convolution reads the
+    output -- an un-normalised output with a sign-only activation may then exist as {hi, lo} planes alone (bounded split)."""
     xsplit = wsplit = out_split = None
     no_f32 = bool(getattr(x, "_cg_no_f32", False))
     if upsample and _upconv_ok(tuple(x.shape), weight, stride, pad, act, x2, wmgr) and wmgr.get(weight) is not None:
@@ -542,15 +608,28 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=
                       weight.shape[0] % 32 == 0) else None
     if no_f32 and (xsplit is None or wsplit is None):
         raise hip.HipError("an activation produced in split form only reached a convolution that reads fp32")
+    # bounded split: an un-normalised output (no norm follows, the input itself carries a device-side scale) that the next
+    # convolution will read leaves the kernel as {hi, lo} planes on an a-priori scale
+    bounded = None
+    if (BOUNDED_SPLIT and want_split and stats is None and out_split is None and xsplit is not None and wsplit is not None
+            and xsplit.state is not None and weight.shape[0] % 32 == 0 and x3_interleaved()):
+        bounded = wmgr.l1_bound(weight, bias, _grp(weight), _G.n, False)
+        if bounded is not None:
+            out_split, amax_out = [], None
     dz_ok = [] if (stats is not None and X3_BACKWARD and xsplit is not None) else None      # a norm follows
+    bwd_want = [] if (stats is None and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)) else None
     y = _Conv2d.apply(x, x2, weight, bias, getattr(weight, "_cg_grad", None),
                       getattr(bias, "_cg_grad", None) if bias is not None else None,
                       int(stride), int(pad), ACT[act], bool(upsample), stats, xsplit, wsplit, out_split, amax_out, wmgr,
-                      (_grp(weight), weight), dz_ok, no_f32)
+                      (_grp(weight), weight), dz_ok, no_f32, bounded, getattr(x, "_cg_bwd", None), bwd_want, bool(want_f32))
     if dz_ok:
         y._cg_dz_split_ok = True
+    if bwd_want:
+        y._cg_bwd = bwd_want[0]      # (activation, dz wanted as planes, dz wanted in fp32) -- read by the consumer's backward
     if out_split:
         y._cg_split = out_split[0]
+        if len(out_split) > 1:
+            y._cg_no_f32 = True
     if amax_out:
         y._cg_amax = amax_out[0]
     return y
@@ -783,9 +862,10 @@ class SplitTensor:
     lo halves sit `lo` halves after the hi halves (x3_lo); `scale` is the power of two s the values were multiplied by
     (weights: hip.X3_WSCALE)."""
 
-    def __init__(self, buf, shape, off=0, lo=None, scale=1.0, state=None):
+    def __init__(self, buf, shape, off=0, lo=None, scale=1.0, state=None, nslots=0):
         self.buf, self.shape, self.off, self.scale = buf, tuple(shape), off, scale
-        self.state = state      # device float[2] of a dynamically scaled tensor: [1] = the power-of-two scale in use
+        self.state = state      # device floats of a dynamically scaled tensor: [0] = max |x| (or its bound), [1] = the scale in use
+        self.nslots = nslots    # > 0: state[2 .. 2 + nslots) holds per-block maxima of x nobody has reduced into state[0]
         n = 1
         for d in shape:
             n *= d
@@ -887,6 +967,22 @@ class SplitWeights:
             self._dgrad[key] = wt
         return wt
 
+    def l1_bound(self, weight, bias, grp, n, by_ci):
+        """Device float[2] {largest row (by_ci = False) / column (True) 1-norm of `weight` over the members of the scope, largest
+        |bias|} for the current weight version (cg_weight_l1_bound): the a-priori bound of a bounded-split epilogue."""
+        if not self.refresh() or id(weight) not in self.views:
+            return None
+        key = (id(weight), 'l1', bool(by_ci), n)
+        t = self._dgrad.get(key)
+        if t is None:
+            t = torch.empty(2, dtype=torch.float32, device=weight.device)
+            ws = workspace(_lib().cg_weight_l1_workspace(weight.shape[1], n), slot=3) if by_ci else None
+            check(_lib().cg_weight_l1_bound(grp, ptr(nhwc(weight)), weight.shape[0], weight.shape[2] * weight.shape[3],
+                                            weight.shape[1], None if by_ci else ptr(bias), int(bool(by_ci)), ptr(t), ptr(ws),
+                                            ws.numel() if ws is not None else 0, stream()), "cg_weight_l1_bound")
+            self._dgrad[key] = t
+        return t
+
     def upconv_weights(self, weight, grp, n):
         """(wt_fwd, wt_bwd): the summed-tap {hi, lo} weights of an upsample + 3x3 layer (cg_upconv_prep_x3) for the current
         weight version and member scope -- one launch pair per (layer, version)."""
@@ -956,7 +1052,7 @@ def act_bwd_split(dy, y, act, want_fp32, amax=None):
     return dz, SplitTensor(buf, dy.shape, state=state)
 
 
-def conv_dgrad_x3(g, dz, w, ci0, nci, grp=None, weight=None, wmgr=None, nm=1):
+def conv_dgrad_x3(g, dz, w, ci0, nci, grp=None, weight=None, wmgr=None, nm=1, fuse=None, xsplit=None):
     """conv_dgrad on the split-precision kernel: dz is split with its device-side scale; needs Cout % 32 == 0.  The weights
     are re-laid-out and split per launch into the workspace -- or, for a parameter of a SplitWeights-managed optimizer
     (`weight`, `wmgr`), once per weight version (SplitWeights.dgrad_weights)."""
@@ -965,6 +1061,33 @@ def conv_dgrad_x3(g, dz, w, ci0, nci, grp=None, weight=None, wmgr=None, nm=1):
     dzs = dz if isinstance(dz, SplitTensor) else split_f16_dynamic(dz)
     dxl = torch.empty((N, nci, H << up, W << up), dtype=torch.float32, device=dzs.buf.device, memory_format=CL)
     wt = wmgr.dgrad_weights(weight, w, g, ci0, nci, grp, nm) if (wmgr is not None and weight is not None) else None
+    if wt is not None and fuse is not None and xsplit is not None and dzs.state is not None and not up and x3_interleaved():
+        # The layer below (the producer of this layer's input x) has a sign-only activation fused into its convolution and asked
+        # for dz = dx * act'(x) directly: fold the activation backward into this data gradient's epilogue (the sign comes from
+        # x's hi plane) and, when that layer reads dz as {hi, lo} planes, write them on the a-priori scale
+        # L1(columns of W) * max|dz_in| -- no fp32 dx, no activation / split pass over it (cg_x3_epilogue)
+        act_b, want_split, want_f32, cell = fuse
+        ctl = wmgr.l1_bound(weight, None, grp, nm, True) if want_split else None
+        if not want_split or ctl is not None:
+            cell[0] += 1
+            state = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=dxl.device)
+            buf = torch.empty(2 * dxl.numel(), dtype=torch.float16, device=dxl.device) if want_split else None
+            epi = hip.X3Epilogue(ctl.data_ptr() if want_split else None, dzs.state.data_ptr(), int(dzs.nslots), int(act_b),
+                                 xsplit.hi_ptr(), state.data_ptr())
+            nslots = ctypes.c_int(0)
+            check(lib.cg_conv2d_dgrad_x3_run_e(byref(g), grp, dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), ptr(wt), 1.0, wmgr.scale_ptr(),
+                                               ci0, nci, ptr(dxl) if want_f32 else None, ptr(buf), x3_lo(dxl.numel()),
+                                               byref(epi), ptr(state), byref(nslots), stream()), "cg_conv2d_dgrad_x3_run_e")
+            if want_split:
+                if nslots.value == 0:
+                    raise hip.HipError("fused activation backward: the kernel reported no output maxima")
+                dxl._cg_dz_split = SplitTensor(buf, dxl.shape, state=state, nslots=nslots.value)
+                dxl._cg_dz_version = dxl._version
+            elif nslots.value:
+                dxl._cg_amax = (state, nslots.value, dxl._version)
+            dxl._cg_act_applied = dxl._version
+            dxl._cg_has_f32 = bool(want_f32)
+            return dxl
     if wt is not None:
         # the kernel leaves the per-block maxima of dx behind: the layer below splits its dz without measuring it again
         state = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=dxl.device) if not up else None

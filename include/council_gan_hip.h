@@ -199,6 +199,40 @@ int cg_upconv_fold_dw(const cg_group* group, const float* dwf, float* dw, int Co
 size_t cg_colsum_split_workspace(int C, int nmember);
 int cg_colsum_split(const cg_group* group, const void* z_split, size_t lo_elems, const float* scale_dev, long rows_total, int C,
                     float* db, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream);
+/* ---- bounded split: un-normalised outputs leave the split-precision kernels as {hi, lo} planes -------------------------------
+ * A discriminator activation (networks.py:44-52, 142-152: Conv2dBlock + LeakyReLU, no norm) or a gradient has no natural scale,
+ * so its consumer used to measure it and split it in a pass of its own (cg_split_f16_dynamic).  A bound is known BEFORE the
+ * producing kernel runs: |y| <= L1 * max|x| + max|bias| with L1 = the largest row (forward) / column (data gradient) 1-norm of
+ * the weights (cg_weight_l1_bound, once per weight version) and max|x| = the measured maximum the input's producer left behind.
+ * Every block derives the same power-of-two scale 2^(14 - floor(log2 bound)) from it and the epilogue writes the planes --
+ * overflow-free by construction, the scaled peak in practice 2^3 ... 2^6 below 2^15 (signed sums do not reach their 1-norm
+ * bound), i.e. every element within 2^-12 of the peak still carries 22 bits.  No reference counterpart (the reference keeps fp32).
+ *   l1_ctl     device float[2] from cg_weight_l1_bound; NULL: no bounded split (act_src may still be set)
+ *   in_state   split state of the INPUT operand: [0] = its measured max |x| -- or, in_nslots > 0: [2 .. 2 + in_nslots) holds
+ *              per-block maxima a producer left (cg_conv2d_fwd_x3_e itself, cg_conv2d_fwd_amax, cg_instnorm_bwd ...)
+ *   act_src    hi plane ({hi, lo} form, same geometry as the output) of the tensor the output is the gradient OF; the output is
+ *              multiplied by act'(act_src), act_type = CG_ACT_RELU / CG_ACT_LRELU (sign-only derivatives): the activation
+ *              backward of the layer below, fused into the data-gradient epilogue (trainer_council.py:779,882 loss.backward())
+ *   out_state  CG_SPLIT_STATE_FLOATS floats: [0] = the bound, [1] = the scale of the planes, [2 ..] = block maxima of the outputs */
+typedef struct cg_x3_epilogue {
+    const float* l1_ctl;
+    const float* in_state;
+    int32_t in_nslots;
+    int32_t act_type;
+    const void* act_src;
+    float* out_state;
+} cg_x3_epilogue;
+size_t cg_weight_l1_workspace(int Cin, int nmember);      /* for by_input_channel = 1 (deterministic two-stage column sums) */
+int cg_weight_l1_bound(const cg_group* group, const float* w, int Cout, int T, int Cin, const float* bias, int by_input_channel,
+                       float* out2, void* ws, size_t ws_bytes, cg_stream_t stream);
+int cg_conv2d_fwd_x3_e(const cg_conv_geom* g, const cg_group* group, const void* x_split, size_t x_lo_elems, const void* w_split,
+                       size_t w_lo_elems, float w_scale, const float* w_scale_dev, const float* x_scale_dev, const float* bias,
+                       float* y /* may be NULL */, void* y_split, size_t y_lo_elems, const cg_x3_epilogue* epi, int tile_cfg,
+                       int* amax_nslots, cg_stream_t stream);
+int cg_conv2d_dgrad_x3_run_e(const cg_conv_geom* g, const cg_group* group, const void* dz_split, size_t dz_lo_elems,
+                             const float* dz_scale_dev, const void* wt, float w_scale, const float* w_scale_dev, int ci0, int nci,
+                             float* dx /* may be NULL */, void* dx_split, size_t dx_lo_elems, const cg_x3_epilogue* epi,
+                             float* amax_state, int* amax_nslots, cg_stream_t stream);
 /* split-precision weight gradient: cg_conv2d_wgrad with x and dz given in {hi, lo} form (+ device-side scales,
  * NULL = 1).  cg_conv2d_wgrad_x3_ok(g) != 0 iff the layer qualifies (one source, every k-tile inside one tap,
  * channel counts multiples of 32, power-of-two output plane); workspace as cg_conv2d_wgrad_workspace(g). */

@@ -241,11 +241,14 @@ def test_two_iterations_vs_reference(cga, name):
             # post-step weights: one Adam step moves every weight by <= lr; compare the bulk
             ref_ws = g[pre + "%s/postsum/%s/%d" % (kind, d, i)]
             minew = summary(ws)
-            assert np.all(np.abs(minew[:, 1] - ref_ws[:, 1]) <= 1e-4 * ref_ws[:, 1] + 3e-4), (kind, d, i)
-            # tensors whose gradient is round-off noise (conv biases feeding an instance norm) take
-            # Adam-normalised random steps of size ~lr in the reference too: excluded
+            # tensors whose gradient is round-off noise (conv biases feeding an instance norm: the exact gradient is zero) take
+            # Adam-normalised random steps of size ~lr in the reference too -- their norm after two steps is a random walk
+            # (lr * sqrt(n) * O(1)), not a quantity two fp32 evaluations share: excluded here and below
             gkeys = sorted(gs)
             noisy = {k for k, r in zip(gkeys, ref_sum) if r[1] < 1e-6 * scale}
+            off = np.abs(minew[:, 1] - ref_ws[:, 1]) > 1e-4 * ref_ws[:, 1] + 3e-4
+            bad_w = [(k, float(a), float(b)) for k, a, b, o in zip(sorted(ws), minew[:, 1], ref_ws[:, 1], off) if o and k not in noisy]
+            assert not bad_w, (kind, d, i, bad_w)
             ref_wfull = g.sub(pre + "%s/post/%s/%d/" % (kind, d, i))
             for k, v in ref_wfull.items():
                 if k not in noisy:

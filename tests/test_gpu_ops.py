@@ -1214,3 +1214,78 @@ def test_upsample_conv_as_transposed_conv(cga, shape, n):
         assert rel(xi.grad[rows], xr.grad) < TOL, ("data gradient", m)
         assert rel(convs[m].weight._cg_grad, wr.grad) < TOL, ("weight gradient", m)
         assert rel(convs[m].bias._cg_grad, br.grad) < TOL, ("bias gradient", m)
+
+
+@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("first", ["thin3", "x3"])
+def test_bounded_split_chain_and_fused_activation_backward(cga, n, first, monkeypatch):
+    """A discriminator-like chain conv+LeakyReLU x 3 -> 1x1 (networks.py:44-52, no norm) on the split-precision path with the
+    round-4 epilogue extras (cg_x3_epilogue): every un-normalised output leaves its kernel as {hi, lo} planes on the a-priori
+    scale L1(W) * max|x| + max|b| (no measuring / splitting pass, no fp32 copy), and every activation backward is folded into
+    the data-gradient epilogue of the layer above.  Against fp64 torch: outputs, data gradient, every weight / bias gradient;
+    and against the same chain with the extras off (CG_BOUNDED_SPLIT=0-style switches): same numbers to 2e-6."""
+    from council_gan_amd import ops
+    from council_gan_amd.optim import ParamPool
+    B, H = 2, 32
+    cin = 3 if first == "thin3" else 64
+    chans = [(cin, 64, 4, 2, 1, "lrelu"), (64, 128, 4, 2, 1, "lrelu"), (128, 256, 4, 2, 1, "lrelu"), (256, 256, 1, 1, 0, "none"),
+             (256, 1, 1, 1, 0, "none")]
+
+    def build():
+        torch.manual_seed(5)
+        nets = [[torch.nn.Conv2d(ci, co, k, s, bias=True) for ci, co, k, s, p, a in chans] for _ in range(n)]
+        for m, net in enumerate(nets):
+            for c in net:
+                with torch.no_grad():
+                    c.weight.mul_(1.0 + 0.3 * m)
+                    c.bias.normal_(0, 0.1)
+        pool = ParamPool([cga.FlatAdam([p for c in net for p in c.parameters()], lr=1e-4) for net in nets])
+        pool.materialize('cuda')
+        return nets, pool, ops.SplitWeights(pool)
+
+    torch.manual_seed(9)
+    x = cl((torch.rand(n * B, cin, H, H) * 2 - 1).cuda())
+    gy = None
+    saved = (ops.X3_FORWARD, ops.X3_BACKWARD, ops.X3_DYNAMIC_INPUT)
+    ops.X3_FORWARD = ops.X3_BACKWARD = ops.X3_DYNAMIC_INPUT = True
+    results = {}
+    try:
+        for mode in ("on", "off"):
+            monkeypatch.setattr(ops, "BOUNDED_SPLIT", mode == "on")
+            monkeypatch.setattr(ops, "FUSED_ACT_BWD", mode == "on")
+            nets, pool, mgr = build()
+            xi = x.clone().requires_grad_(True)
+            h = xi
+            used = []
+            with ops.members(n):
+                for li, (ci, co, k, s, p, a) in enumerate(chans):
+                    c = nets[0][li]
+                    h = ops.conv2d(h, c.weight, c.bias, s, p, a, wmgr=mgr, want_split=(co % 32 == 0), want_f32=(li == len(chans) - 1))
+                    used.append((getattr(h, "_cg_no_f32", False), getattr(h, "_cg_split", None) is not None))
+            if gy is None:
+                torch.manual_seed(10)
+                gy = torch.randn(h.shape).cuda()
+            h.backward(gy)
+            torch.cuda.synchronize()
+            results[mode] = (h.detach().clone(), xi.grad.clone(), pool.grad.clone(), used, nets)
+    finally:
+        ops.X3_FORWARD, ops.X3_BACKWARD, ops.X3_DYNAMIC_INPUT = saved
+    y_on, dx_on, g_on, used_on, nets = results["on"]
+    y_off, dx_off, g_off, used_off, _ = results["off"]
+    # the extras were in effect: the second and third LeakyReLU layers exist as planes only, nothing does with the switches off
+    assert used_on[1] == (True, True) and used_on[2] == (True, True), used_on
+    assert not any(u[0] for u in used_off), used_off
+    assert rel(y_on, y_off) < 2e-6 and rel(dx_on, dx_off) < 2e-6 and rel(g_on, g_off) < 2e-6
+    for m in range(n):
+        rows = slice(m * B, (m + 1) * B)
+        xr = x[rows].detach().double().cpu().requires_grad_(True)
+        ws = [(c.weight.detach().double().cpu().requires_grad_(True), c.bias.detach().double().cpu().requires_grad_(True)) for c in nets[m]]
+        hr = xr
+        for (w, b), (ci, co, k, s, p, a) in zip(ws, chans):
+            hr = ref_act(F.conv2d(hr, w, b, stride=s, padding=p), a)
+        hr.backward(gy[rows].double().cpu())
+        assert rel(y_on[rows], hr) < TOL, ("forward", m)
+        assert rel(dx_on[rows], xr.grad) < TOL, ("data gradient", m)
+        for li, (w, b) in enumerate(ws):
+            assert rel(nets[m][li].weight._cg_grad, w.grad) < TOL, ("weight gradient", m, li)
+            assert rel(nets[m][li].bias._cg_grad, b.grad) < 5 * TOL, ("bias gradient", m, li)

@@ -13,6 +13,7 @@ fi
 DB=$(find $O/raw -name "*.db" | head -1)
 python $R/tools/rocpd_summary.py $DB 70 > $O/kernel_stats.txt 2>&1
 python $R/tools/rocpd_timeline.py $DB 0.4 > $O/timeline.txt 2>&1
+python $R/tools/rocpd_top_dispatches.py $DB 60 > $O/top_dispatches.txt 2>&1
 rm -rf $O/raw
 head -75 $O/kernel_stats.txt
 cat $O/timeline.txt
