@@ -131,7 +131,7 @@ class GpuSampler(threading.Thread):
 def pmc_traffic(kernel):
     """Counter-derived memory-side traffic of `kernel` on its dominant launch, from the committed PMC record
     (profiles/pmc_traffic.json: separate rocprofv3 --pmc passes, FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, per launch;
-    tools/pmc_x3w.sh).  Returns (bytes per launch or None, the record or None)."""
+    PMC=16 bash tools/prof_bench.sh).  Returns (bytes per launch or None, the record or None)."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(kernel)
     except (OSError, ValueError):
@@ -594,7 +594,7 @@ def main():
             if kernel_peak(dname) == F16X3_PEAK_TFLOPS:
                 # what the matrix pipe sustains on this very instruction mix with NO memory traffic at all (3 dependent-free
                 # v_mfma_f32_32x32x16_f16 per product, 8 accumulators per wave, one block per CU, power-limited clock):
-                # committed measurement, tools/probe/mfma_mix.hip -> profiles/r03_mfma_mix.txt
+                # committed measurement, tools/attic/probe/mfma_mix.hip -> profiles/r03_mfma_mix.txt
                 roof["pipe_ceiling"] = {"value": MFMA_MIX_CEILING_TFLOPS, "unit": "TFLOP/s (a.b products)",
                                         "frac": round(ach / MFMA_MIX_CEILING_TFLOPS, 4), "source": "profiles/r03_mfma_mix.txt"}
         else:

@@ -435,6 +435,53 @@ __global__ void ring_kernel(float* __restrict__ ring_a, float* __restrict__ ring
     }
 }
 
+// ---- two 1x1 convolutions with nothing between them, composed (MsImageDisCouncil's last two layers, networks.py:142-143:
+//      Conv2d(dim, dim, 1) -> Conv2d(dim, 1, 1), no activation): W2 (W1 y + b1) + b2 = (W2 W1) y + (W2 b1 + b2) -- a dim -> 1
+//      convolution instead of a dim -> dim one.  out (per member, stride S floats): [0, C) = w_eff, [C] = b_eff.
+__global__ __launch_bounds__(256) void compose1x1_fwd_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
+                                                             const float* __restrict__ W2, const float* __restrict__ b2, int C,
+                                                             long long pstride, float* __restrict__ out, int S) {
+    const int m = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    W1 += (long long)m * pstride; b1 += (long long)m * pstride; W2 += (long long)m * pstride; b2 += (long long)m * pstride;
+    out += (size_t)m * S;
+    if (k < C) {
+        float a = 0.f;
+        for (int j = 0; j < C; ++j) a = fmaf(W2[j], W1[(size_t)j * C + k], a);      // fixed order: deterministic
+        out[k] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float a = b2[0];
+        for (int j = 0; j < C; ++j) a = fmaf(W2[j], b1[j], a);
+        out[C] = a;
+    }
+}
+// d (per member, stride S): [0, C) = d w_eff, [C] = d b_eff  ->  dW1[j][k] += W2[j] d w_eff[k];  db1[j] += W2[j] d b_eff;
+// dW2[j] += sum_k d w_eff[k] W1[j][k] + d b_eff b1[j];  db2 += d b_eff
+__global__ __launch_bounds__(256) void compose1x1_bwd_kernel(const float* __restrict__ d, int S, const float* __restrict__ W1,
+                                                             const float* __restrict__ b1, const float* __restrict__ W2, int C,
+                                                             long long pstride, float* __restrict__ dW1, float* __restrict__ db1,
+                                                             float* __restrict__ dW2, float* __restrict__ db2) {
+    const int m = blockIdx.y, j = blockIdx.x;
+    d += (size_t)m * S;
+    const long long off = (long long)m * pstride;
+    const float w2 = W2[off + j], dbe = d[C];
+    float a = 0.f;
+    for (int k = threadIdx.x; k < C; k += 256) {
+        const float dk = d[k];
+        dW1[off + (size_t)j * C + k] += w2 * dk;
+        a = fmaf(dk, W1[off + (size_t)j * C + k], a);
+    }
+    __shared__ float red[4];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dW2[off + j] += (red[0] + red[1]) + (red[2] + red[3]) + dbe * b1[off + j];
+        db1[off + j] += w2 * dbe;
+        if (j == 0) db2[off] += dbe;
+    }
+}
+
 }  // namespace
 
 #define EW_LAUNCH(kernel, n, ...)                                                                  \
@@ -492,6 +539,24 @@ extern "C" int cg_unsplit_f16(const void* z_split, size_t lo_elems, const float*
     CG_CHECK_ARG(z_split && out, "cg_unsplit_f16: null pointer");
     if (n == 0) return CG_OK;
     EW_LAUNCH(unsplit_f16_kernel, n, (const _Float16*)z_split, lo_elems, scale_dev, out, n);
+}
+extern "C" int cg_compose1x1_fwd(const cg_group* group, const float* W1, const float* b1, const float* W2, const float* b2, int C,
+                                 float* out, int out_stride, cg_stream_t stream) {
+    CG_CHECK_ARG(W1 && b1 && W2 && b2 && out && C > 0 && out_stride > C, "cg_compose1x1_fwd: bad args");
+    const int n = group ? group->n : 1;
+    hipLaunchKernelGGL(compose1x1_fwd_kernel, dim3((C + 255) / 256, n), dim3(256), 0, cg_s(stream), W1, b1, W2, b2, C,
+                       group ? (long long)group->stride : 0, out, out_stride);
+    CG_LAUNCH_CHECK("compose1x1_fwd_kernel");
+    return CG_OK;
+}
+extern "C" int cg_compose1x1_bwd(const cg_group* group, const float* d, int d_stride, const float* W1, const float* b1,
+                                 const float* W2, int C, float* dW1, float* db1, float* dW2, float* db2, cg_stream_t stream) {
+    CG_CHECK_ARG(d && W1 && b1 && W2 && dW1 && db1 && dW2 && db2 && C > 0 && d_stride > C, "cg_compose1x1_bwd: bad args");
+    const int n = group ? group->n : 1;
+    hipLaunchKernelGGL(compose1x1_bwd_kernel, dim3(C, n), dim3(256), 0, cg_s(stream), d, d_stride, W1, b1, W2, C,
+                       group ? (long long)group->stride : 0, dW1, db1, dW2, db2);
+    CG_LAUNCH_CHECK("compose1x1_bwd_kernel");
+    return CG_OK;
 }
 extern "C" int cg_add(const float* a, const float* b, float* out, size_t n, cg_stream_t stream) {
     CG_CHECK_ARG(a && b && out, "cg_add: null pointer");

@@ -75,6 +75,8 @@ _SIGS = {
                                    c_size_t, POINTER(X3Epilogue), c_int, POINTER(c_int), _P]),
     "cg_conv2d_dgrad_x3_run_e": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_size_t, _P, _P, c_float, _P, c_int, c_int, _P, _P,
                                          c_size_t, POINTER(X3Epilogue), _P, POINTER(c_int), _P]),
+    "cg_compose1x1_fwd": (c_int, [POINTER(Group), _P, _P, _P, _P, c_int, _P, c_int, _P]),
+    "cg_compose1x1_bwd": (c_int, [POINTER(Group), _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "cg_unsplit_f16": (c_int, [_P, c_size_t, _P, _P, c_size_t, _P]),
     "cg_upconv_wt_elems": (c_size_t, [c_int, c_int]),
     "cg_upconv_prep_x3": (c_int, [POINTER(Group), _P, c_int, c_int, c_float, _P, _P, _P, _P]),

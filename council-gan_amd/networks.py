@@ -571,12 +571,18 @@ class MsImageDisCouncil(nn.Module):
         outputs = []
         for si, model in enumerate(self.cnns):
             blocks = list(model)
-            y = blocks[0](x, x2=x_input, want_f32=False)      # every block's output is read by the next convolution only
-            for blk in blocks[1:-2]:
-                y = blk(y, want_f32=False)
+            tail = ops.composed_tail_ok(blocks[-2], blocks[-1])
+            y = blocks[0](x, x2=x_input, want_f32=False)      # every block's output is read by the next convolution only ...
+            for k, blk in enumerate(blocks[1:-2]):
+                y = blk(y, want_f32=tail and k == len(blocks) - 4)      # ... except in front of the composed fp32 tail
             wmgr = getattr(self, '_cg_wmgr', None)
-            y = ops.conv2d(y, blocks[-2].weight, blocks[-2].bias, 1, 0, 'none', wmgr=wmgr, want_split=wmgr is not None)
-            outputs.append(ops.conv2d(y, blocks[-1].weight, blocks[-1].bias, 1, 0, 'none', wmgr=wmgr))
+            if tail:
+                # Conv2d(dim, dim, 1) -> Conv2d(dim, 1, 1) with no activation in between (networks.py:142-143) is ONE dim -> 1
+                # convolution with the product of the two weight matrices: the dim -> dim layer is never run
+                outputs.append(ops.composed_tail(y, blocks[-2], blocks[-1]))
+            else:
+                y = ops.conv2d(y, blocks[-2].weight, blocks[-2].bias, 1, 0, 'none', wmgr=wmgr, want_split=wmgr is not None)
+                outputs.append(ops.conv2d(y, blocks[-1].weight, blocks[-1].bias, 1, 0, 'none', wmgr=wmgr))
             if si + 1 < len(self.cnns):
                 x = ops.avgpool3s2(x)
                 x_input = ops.avgpool3s2(x_input)

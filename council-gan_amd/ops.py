@@ -646,6 +646,87 @@ def linear(x, weight, bias=None, act="none"):
 
 
 # ------------------------------------------------------------------------------------------
+# two 1x1 convolutions with nothing between them, composed (the council discriminator's tail, networks.py:142-143)
+# ------------------------------------------------------------------------------------------
+# CG_COMPOSE_1X1=0: the two layers run one after the other (A/B switch)
+COMPOSE_1X1 = os.environ.get("CG_COMPOSE_1X1", "1") != "0"
+_tail_groups = {}
+
+
+def _tail_group(n, stride):
+    if n <= 1:
+        return None
+    g = _tail_groups.get((n, stride))
+    if g is None:
+        g = _tail_groups[(n, stride)] = hip.Group(n, 0, stride)
+    return byref(g)
+
+
+class _ComposedTail(torch.autograd.Function):
+    """conv1x1(conv1x1(y, W1, b1), W2, b2) with W2: C -> 1 and no activation in between, evaluated as ONE C -> 1 convolution
+    with w_eff = W2 W1, b_eff = W2 b1 + b2 (cg_compose1x1_fwd): the C -> C convolution -- forward, data gradient, weight
+    gradient -- is never run; its gradients follow from the composed layer's (cg_compose1x1_bwd).  fp32 throughout."""
+
+    @staticmethod
+    def forward(ctx, y, W1, b1, W2, b2):
+        lib = _lib()
+        y = nhwc(y)
+        N, C, H, W = y.shape
+        n = _G.n
+        grp = _grp(W1)
+        S = C + 32
+        buf = torch.empty(n * S, dtype=torch.float32, device=y.device)
+        check(lib.cg_compose1x1_fwd(grp, ptr(W1), ptr(b1), ptr(W2), ptr(b2), C, ptr(buf), S, stream()), "cg_compose1x1_fwd")
+        g = fwd_geom(N, H, W, C, 0, 0, 1, 1, 1, 0, 1, 0)
+        gt = _tail_group(n, S)
+        out = empty_nhwc(N, 1, H, W, y)
+        check(lib.cg_conv2d_fwd_g(byref(g), gt, ptr(y), None, ptr(buf), _off(buf, C), ptr(out), None, 0, None, None, None, stream()),
+              "cg_conv2d_fwd (composed 1x1 tail)")
+        ctx.save_for_backward(y, W1, b1, W2, buf)
+        ctx.meta = (g, grp, gt, n, S, C)
+        ctx.bufs = tuple(getattr(p, "_cg_grad", None) for p in (W1, b1, W2, b2))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib()
+        y, W1, b1, W2, buf = ctx.saved_tensors
+        g, grp, gt, n, S, C = ctx.meta
+        dout = nhwc(dout)
+        dy = None
+        if ctx.needs_input_grad[0]:
+            dy = torch.empty_like(y)
+            ws = workspace(lib.cg_conv2d_dgrad_workspace_g(byref(g), gt, C))
+            check(lib.cg_conv2d_dgrad_g(byref(g), gt, ptr(dout), ptr(buf), 0, C, ptr(dy), ptr(ws), ws.numel(), stream()),
+                  "cg_conv2d_dgrad (composed 1x1 tail)")
+        if any(ctx.needs_input_grad[1:]):
+            if any(b is None for b in ctx.bufs):
+                raise hip.HipError("composed 1x1 tail: the parameters need pool-backed gradient buffers")
+            d = torch.empty(n * S, dtype=torch.float32, device=y.device)
+            ws = workspace(lib.cg_conv2d_wgrad_workspace_g(byref(g), gt))
+            check(lib.cg_conv2d_wgrad_g(byref(g), gt, ptr(y), None, ptr(dout), ptr(d), _off(d, C), 0, ptr(ws), ws.numel(), stream()),
+                  "cg_conv2d_wgrad (composed 1x1 tail)")
+            gW1, gb1, gW2, gb2 = ctx.bufs
+            check(lib.cg_compose1x1_bwd(grp, ptr(d), S, ptr(W1), ptr(b1), ptr(W2), C, ptr(gW1), ptr(gb1), ptr(gW2), ptr(gb2), stream()),
+                  "cg_compose1x1_bwd")
+            for t in ctx.bufs:
+                t._cg_touched = True
+        return dy, None, None, None, None
+
+
+def composed_tail_ok(c1, c2):
+    """Can the two trailing nn.Conv2d holders run as one composed layer?  1x1, stride 1, C -> C -> 1, pool-managed parameters."""
+    return (COMPOSE_1X1 and c1.kernel_size == (1, 1) and c2.kernel_size == (1, 1) and c1.stride == (1, 1) and c2.stride == (1, 1)
+            and c1.out_channels == c1.in_channels == c2.in_channels and c2.out_channels == 1 and c1.bias is not None
+            and c2.bias is not None and all(getattr(p, "_cg_grad", None) is not None for p in (c1.weight, c1.bias, c2.weight, c2.bias))
+            and getattr(c1.weight, "_cg_pool", None) is not None)
+
+
+def composed_tail(y, c1, c2):
+    return _ComposedTail.apply(y, c1.weight, c1.bias, c2.weight, c2.bias)
+
+
+# ------------------------------------------------------------------------------------------
 # instance norm / AdaIN (+ activation + residual)
 # ------------------------------------------------------------------------------------------
 class _InstNormAct(torch.autograd.Function):

@@ -187,6 +187,16 @@ int cg_conv2d_dgrad_x3_run(const cg_conv_geom* g, const cg_group* group, const v
  *                        dw at group->stride).
  *   cg_colsum_split:     db[c] (+)= sum over rows of a {hi, lo} tensor [rows_total][C] / *scale_dev -- the bias gradient of a layer
  *                        whose dz exists in split form only (rows_total = all members' rows, member-major). */
+/* Two 1x1 convolutions with nothing between them, composed: the council discriminator ends in Conv2d(dim, dim, 1) -> Conv2d(dim, 1, 1)
+ * with no activation in between (networks.py:142-143), i.e. W2 (W1 y + b1) + b2 = (W2 W1) y + (W2 b1 + b2): one dim -> 1 convolution.
+ *   cg_compose1x1_fwd: out (per member, out_stride floats) = {w_eff[0 .. C), b_eff}; W1 [C][C] (row = output channel), W2 [C].
+ *   cg_compose1x1_bwd: d = {d w_eff, d b_eff} (the gradients the dim -> 1 convolution produced) -> ACCUMULATES dW1[j][k] += W2[j] d
+ *                      w_eff[k], db1[j] += W2[j] d b_eff, dW2[j] += sum_k d w_eff[k] W1[j][k] + d b_eff b1[j], db2 += d b_eff.
+ * Members: the four parameters and their gradient buffers at group->stride (one optimizer pool). */
+int cg_compose1x1_fwd(const cg_group* group, const float* W1, const float* b1, const float* W2, const float* b2, int C, float* out,
+                      int out_stride, cg_stream_t stream);
+int cg_compose1x1_bwd(const cg_group* group, const float* d, int d_stride, const float* W1, const float* b1, const float* W2, int C,
+                      float* dW1, float* db1, float* dW2, float* db2, cg_stream_t stream);
 /* {hi, lo} planes -> fp32: out[i] = (hi[i] + lo[i]) / *scale_dev (scale_dev NULL = 1) in the tensor's physical element order */
 int cg_unsplit_f16(const void* z_split, size_t lo_elems, const float* scale_dev, float* out, size_t n, cg_stream_t stream);
 size_t cg_upconv_wt_elems(int Cout, int Cin);

@@ -41,7 +41,7 @@ for st in "$@"; do
       cfgs=${arg%%:*}
       timeout -k 5 180 python tools/ab_x3.py $cfgs 12 < /dev/null > $O/${n}_ab_x3.txt 2>&1; cut -c1-260 $O/${n}_ab_x3.txt; echo "t=$(el)" ;;
     pmc_x3w)  # pmc_x3w:<cfg>
-      timeout -k 5 170 bash tools/pmc_x3w.sh ${O#gpurun_out/}/${n}_pmc_cfg$arg $arg < /dev/null > $O/${n}_pmc.log 2>&1; tail -4 $O/${n}_pmc.log | cut -c1-400; echo "t=$(el)" ;;
+      PMC=$arg timeout -k 5 170 bash tools/prof_bench.sh ${O#gpurun_out/}/${n}_pmc_cfg$arg < /dev/null > $O/${n}_pmc.log 2>&1; tail -4 $O/${n}_pmc.log | cut -c1-400; echo "t=$(el)" ;;
     py)  # py:<script>[,args]   any tool under tools/
       timeout -k 5 240 python ${arg//,/ } < /dev/null > $O/${n}_py.txt 2>&1; tail -40 $O/${n}_py.txt | cut -c1-260; echo "t=$(el)" ;;
     *) echo "unknown stage $st" ;;

@@ -11,7 +11,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import council_gan_amd as cga  # noqa: E402,F401
 from council_gan_amd import hip, ops  # noqa: E402
-from bench_x3 import split, run_x3  # noqa: E402
+from ab_x3 import split, run_x3  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 PCFG = int(sys.argv[2]) if len(sys.argv) > 2 else 29
