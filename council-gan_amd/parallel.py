@@ -160,6 +160,22 @@ class CouncilShard:
             t.mul_(1.0 / self.dp)
         return t
 
+    def replica_mean_begin(self, t):
+        """Start the in-place replica mean of `t` WITHOUT making the current stream wait for it (RCCL through torch.distributed:
+        an asynchronous all-reduce ordered behind what the current stream has queued so far); every other transport does the
+        whole mean now.  Returns a handle for replica_mean_end, or None when there is nothing left to wait for."""
+        if self.dp == 1:
+            return None
+        if self.member_comm is None and t.is_cuda and _is_nccl(self.member_group):
+            return (dist.all_reduce(t, group=self.member_group, async_op=True), t)
+        self.replica_mean_(t)
+        return None
+
+    def replica_mean_end(self, handle):
+        if handle is not None:
+            handle[0].wait()                       # the current stream continues behind the collective
+            handle[1].mul_(1.0 / self.dp)
+
     # ---- the image exchange -------------------------------------------------------------------------------------
     def exchange(self, local_images):
         """local_images: list (len = per_rank) of logical-NCHW tensors (channels_last or contiguous).

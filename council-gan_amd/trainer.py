@@ -281,6 +281,9 @@ class Council_Trainer(nn.Module):
         dflt = '1' if ((self.shard.world_size > 1 and self.shard.dp == 1) or self.council_size == 1) else '0'
         self._graph_mode = str(self._hp_cfg.get('cg_graph', os.environ.get('CG_GRAPH', dflt))) == '1' and self.shard.dp == 1
         self._graph_warmup = max(1, int(os.environ.get('CG_GRAPH_WARMUP', '1')))
+        # replicas of a member: all-reduce the decoder's gradient bucket under the encoder's backward (CG_DP_OVERLAP=0: one
+        # all-reduce of the whole flat gradient after the backward)
+        self._dp_overlap = os.environ.get('CG_DP_OVERLAP', '1') != '0'
         self._hin = HostInputs(dev)
         self._segs, self._recording, self._gx = {}, None, {}
         self._iter_eager, self._phase = True, 0
@@ -662,10 +665,35 @@ class Council_Trainer(nn.Module):
         v = loss.detach()
         return self.shard.replica_mean_(v.clone()) if self.shard.dp > 1 else v
 
-    def _sync_grads(self, pool, k0, g):
-        """Full-batch gradient = mean of the member replicas' gradients: one all-reduce of the members' gradient slices."""
-        if self.shard.dp > 1:
-            self.shard.replica_mean_(pool.grad[k0 * pool.stride:(k0 + g) * pool.stride])
+    def _sync_grads(self, pool, k0, g, early=()):
+        """Full-batch gradient = mean of the member replicas' gradients: one all-reduce of the members' gradient slices -- or,
+        when `early` names ranges whose all-reduce was started during the backward (_dec_bucket), the finish of those and one
+        all-reduce per remaining piece."""
+        if self.shard.dp <= 1:
+            return
+        lo, hi = k0 * pool.stride, (k0 + g) * pool.stride
+        done = sorted((a, b) for a, b, _ in early)
+        for _, _, h in early:
+            self.shard.replica_mean_end(h)
+        pos = lo
+        for a, b in done + [(hi, hi)]:
+            if a > pos:
+                self.shard.replica_mean_(pool.grad[pos:a])
+            pos = max(pos, b)
+
+    def _dec_bucket(self, d, i):
+        """[start, end) of generator (d, i)'s DECODER parameters inside the generator pool's flat buffers: the bucket whose
+        gradient is complete as soon as the content code's gradient exists (every decoder layer's backward has run by then;
+        the style MLP, fed by all AdaIN layers, is not part of it)."""
+        pool = self._pools['gen']
+        gen = self._nets('gen', d)[i]
+        dec, mlp = list(gen.dec.parameters()), list(gen.mlp.parameters())
+        k, pi = pool.index_of(dec[0])
+        k2, pj = pool.index_of(mlp[0])
+        offs = pool.opts[k].flat['offs']
+        if k != k2 or pj != pi + len(dec):
+            return None                       # not laid out [.. decoder | mlp ..]: no early bucket
+        return k * pool.stride + offs[pi], k * pool.stride + offs[pj]
 
     def _upload(self, t):
         """Host tensor -> device without stalling the host: a pageable-memory copy blocks until the stream has drained,
@@ -991,11 +1019,20 @@ class Council_Trainer(nn.Module):
             for grp in groups:
                 g, lead, k0 = len(grp), grp[0], self.shard.local.index(grp[0])
                 with self._on(lead, groups), ops.members(g):
-                    roots, ups, totals = [], [], []
+                    roots, ups, totals, early = [], [], [], []
                     for d in self._dirs:
                         gen = self._nets('gen', d)[lead]
                         xr = self._rep(x[d], g)
                         content_in = self._content(d, grp, xr, need_grad=True)
+                        if self.shard.dp > 1 and self._dp_overlap and g == 1:
+                            # replicas: the decoder's share of the flat gradient (about half of it) is complete when the content
+                            # code's gradient arrives -- start its all-reduce there, under the encoder's backward
+                            rng = self._dec_bucket(d, lead)
+                            if rng is not None:
+                                def _start(grad, rng=rng):
+                                    early.append(rng + (self.shard.replica_mean_begin(pool.grad[rng[0]:rng[1]]),))
+                                    return grad
+                                content_in.register_hook(_start)
                         x_fake = gen.decode(content_in, s_dev[(d, g)], xr)
                         mask = gen.dec.mask_s
                         ftot = adv = lc = w_dev = None
@@ -1054,7 +1091,7 @@ class Council_Trainer(nn.Module):
                         out['loss_gen_total_s'][i] = tot
                     torch.autograd.backward(roots, ups)
                     ops.wgrad_join()
-                    self._sync_grads(pool, k0, g)
+                    self._sync_grads(pool, k0, g, early)
                     self._step(pool, k0, g, hyper)
         finally:
             self._join()

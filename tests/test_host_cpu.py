@@ -434,3 +434,58 @@ def test_input_oracle_matches_the_pil_fixture():
     for n in range(len(z["images"])):
         got = IO.sample(z["images"][n], int(z["tops"][n]), int(z["lefts"][n]), H, W, flip_first=bool(z["flips"][n]))
         assert got.dtype == torch.float32 and np.array_equal(got.numpy(), z["out"][n]), n
+
+
+def test_upsample_conv_equals_the_summed_tap_transposed_conv():
+    """The algebra behind cg_upconv_* (include/council_gan_hip.h): nn.Upsample(2x nearest) -> ZeroPad2d(1) -> Conv2d(3x3)
+    (/root/reference/networks.py:385-386, 513-516) equals conv_transpose2d(x, W_F, stride 2, padding 1) with the 4x4 kernel
+    W_F[u][v] = sum_{kh in S(u), kw in S(v)} W[kh][kw], S(0) = {2}, S(1) = {1, 2}, S(2) = {0, 1}, S(3) = {0}; its input gradient is
+    conv2d(dz, W_F, stride 2, padding 1) and the 3x3 weight gradient is the fold of the 4x4 one.  fp64 torch on the CPU: this pins
+    the tap sets the device code hard-wires (csrc/conv_gemm.hip: upc_first / upc_count)."""
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    S = {0: (2,), 1: (1, 2), 2: (0, 1), 3: (0,)}
+    x = torch.randn(2, 5, 6, 7, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(4, 5, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(4, dtype=torch.float64)
+    y = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+    wf = torch.zeros(5, 4, 4, 4, dtype=torch.float64)              # conv_transpose2d weight: [Cin][Cout][4][4]
+    for u in range(4):
+        for v in range(4):
+            wf[:, :, u, v] = sum(w.detach()[:, :, kh, kw] for kh in S[u] for kw in S[v]).t()
+    wf.requires_grad_(True)
+    xt = x.detach().clone().requires_grad_(True)
+    yt = F.conv_transpose2d(xt, wf, b, stride=2, padding=1)
+    assert yt.shape == y.shape and float((yt - y).abs().max()) < 1e-12
+    dz = torch.randn_like(y)
+    y.backward(dz)
+    yt.backward(dz)
+    assert float((xt.grad - x.grad).abs().max()) < 1e-12
+    # data gradient = the 4x4 stride-2 pad-1 convolution over dz with W_F as [Cin][Cout][4][4] -> conv2d weight [Cin][Cout][4][4]
+    dx = F.conv2d(dz, wf.detach(), stride=2, padding=1)
+    assert float((dx - x.grad).abs().max()) < 1e-12
+    # fold of the 4x4 weight gradient back onto the nine taps
+    dw = torch.zeros_like(w)
+    for u in range(4):
+        for v in range(4):
+            for kh in S[u]:
+                for kw in S[v]:
+                    dw[:, :, kh, kw] += wf.grad[:, :, u, v].t()
+    assert float((dw - w.grad).abs().max()) < 1e-11
+    # the device code's closed form of S(u): first = {2, 1, 0, 0}[u], count = {1, 2, 2, 1}[u]
+    for u in range(4):
+        first, count = (2, 1, 0, 0)[u], (1, 2, 2, 1)[u]
+        assert tuple(range(first, first + count)) == S[u]
+
+
+def test_bounded_split_scale_rule():
+    """cg_x3_epilogue's a-priori scale (csrc/conv_x3.inc: x3_bound_scale): 2^(14 - floor(log2 bound)) puts scale * bound into
+    [2^14, 2^15) -- below fp16's largest finite value with a binade to spare -- for any bound a float can hold between the clamps."""
+    import math
+    for bound in (1e-20, 3e-7, 0.02, 0.99999, 1.0, 1.5, 65.0, 4096.0, 3e9, 1e20):
+        e = math.floor(math.log2(bound))
+        se = min(max(14 - e, 27 - 127), 227 - 127)
+        s = 2.0 ** se
+        if 27 - 127 < 14 - e < 227 - 127:
+            assert 2 ** 14 <= s * bound < 2 ** 15
+        assert s * bound < 65504 or 14 - e < 27 - 127
