@@ -76,11 +76,20 @@ def main():
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) * 1e3 / args.steps
         gpu = e0.elapsed_time(e1) / args.steps
+        # the host's OWN cost of an iteration: step() against an empty queue (synchronize first), so that nothing in it waits for
+        # the GPU -- in the free-running loop above the host is simply held back by the staging ring once it is ~3 iterations ahead
+        own = 0.0
+        for it in range(5):
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            step(4 + args.steps + it)
+            own += time.perf_counter() - h0
+        torch.cuda.synchronize()
         print("rank 0 of %d (council %d, %d member(s) per rank, batch %d, %dx%d)  graph=%s:  %.2f ms per iteration (events), "
-              "wall %.2f ms, host in step() %.2f ms (graph mode: mostly waiting on the upload ring once ~3 iterations ahead)  ->  "
-              "%d ranks: %.1f images/s before the exchange"
-              % (args.world, args.council, per, args.batch, args.size, args.size, graph, gpu, wall, host * 1e3 / args.steps,
-                 args.world, 1e3 * args.batch / max(gpu, wall)), flush=True)
+              "wall %.2f ms; host: %.2f ms per iteration of its own work (step() against an empty queue), %.2f ms inside step() when "
+              "free-running (the rest is back-pressure from the staging ring)  ->  %d ranks: %.1f images/s before the exchange"
+              % (args.world, args.council, per, args.batch, args.size, args.size, graph, gpu, wall, own * 1e3 / 5,
+                 host * 1e3 / args.steps, args.world, 1e3 * args.batch / max(gpu, wall)), flush=True)
         if args.shapes and graph == "0":
             side, tr._overlap = tr._overlap, False          # serialised: a launch's events see only that launch
             try:
