@@ -489,3 +489,61 @@ def test_bounded_split_scale_rule():
         if 27 - 127 < 14 - e < 227 - 127:
             assert 2 ** 14 <= s * bound < 2 ** 15
         assert s * bound < 65504 or 14 - e < 27 - 127
+
+
+def _header_prototypes():
+    """{name: (return class, [parameter classes])} parsed from include/council_gan_hip.h; classes: 'p' pointer / cg_stream_t,
+    'i' int / unsigned, 'f' float, 'd' double, 'q' size_t and the other 64-bit integers."""
+    hdr = open(os.path.join(ROOT, "include", "council_gan_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", " ", hdr)
+
+    def cls(decl):
+        decl = decl.strip()
+        if "*" in decl or re.search(r"\bcg_stream_t\b", decl) or "[" in decl:
+            return "p"
+        if re.search(r"\bsize_t\b", decl):           # ctypes.c_size_t IS c_ulong here: one class for every 64-bit integer
+            return "q"
+        if re.search(r"\b(u?int64_t|long long|unsigned long long|long|unsigned long)\b", decl):
+            return "q"
+        if re.search(r"\bdouble\b", decl):
+            return "d"
+        if re.search(r"\bfloat\b", decl):
+            return "f"
+        if re.search(r"\b(int|unsigned|uint32_t|int32_t)\b", decl):
+            return "i"
+        raise AssertionError("unclassified parameter: %r" % decl)
+
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(cg_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", hdr):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("typedef"):
+            continue
+        params = [] if args in ("", "void") else [cls(a) for a in args.split(",")]
+        protos[name] = (cls(ret) if ret != "void" else "v", params)
+    return protos
+
+
+def test_ctypes_signatures_match_the_header():
+    """Every entry point's ctypes declaration (council_gan_amd/hip.py) against its prototype in include/council_gan_hip.h:
+    parameter count and the class of every parameter -- an int bound where the header says size_t or float would pass the
+    symbol test and corrupt the call on the GPU box."""
+    import ctypes as C
+    protos = _header_prototypes()
+    assert set(protos) == set(cga.hip.EXPORTS), set(protos) ^ set(cga.hip.EXPORTS)
+
+    def cls(t):
+        if t is None:
+            return "v"
+        if t in (C.c_void_p, C.c_char_p) or hasattr(t, "_type_") and not isinstance(t._type_, str):
+            return "p"               # POINTER(struct / int / ...)
+        return {C.c_int: "i", C.c_uint: "i", C.c_float: "f", C.c_double: "d", C.c_size_t: "q", C.c_int64: "q",
+                C.c_uint64: "q", C.c_longlong: "q", C.c_ulonglong: "q", C.c_long: "q", C.c_ulong: "q"}[t]
+
+    bad = []
+    for name, (res, args) in cga.hip._SIGS.items():
+        want_ret, want = protos[name]
+        got = [cls(a) for a in args]
+        if got != want or cls(res) != want_ret:
+            bad.append((name, want_ret + ":" + "".join(want), cls(res) + ":" + "".join(got)))
+    assert not bad, bad
