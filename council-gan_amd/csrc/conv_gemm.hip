@@ -2924,30 +2924,43 @@ __global__ __launch_bounds__(256) void upconv_fold_kernel(const float* __restric
 // (member, row chunk) writes C partial sums, a second launch adds the chunks in a fixed order
 __global__ __launch_bounds__(256) void colsum_split_kernel(const _Float16* __restrict__ zs, unsigned lo_elems, int rows, int C,
                                                            int chunks, float* __restrict__ part) {
+    // a thread owns 8 consecutive channels (one 16-byte load per plane and row: cg_il keeps 8-aligned runs contiguous), C / 8
+    // threads a row, 256 / (C / 8) rows in flight per block; rows of a chunk are summed in a fixed order
     const int member = blockIdx.y, chunk = blockIdx.x;
     const int per = (rows + chunks - 1) / chunks;
     const int r0 = chunk * per, r1 = min(rows, r0 + per);
-    const int c = threadIdx.x % C, rr = threadIdx.x / C, rstep = 256 / C;      // C <= 256, 256 % C == 0
-    float a = 0.f;
+    const int tpr = C >> 3, cg = threadIdx.x % tpr, rr = threadIdx.x / tpr, rstep = 256 / tpr;      // C % 8 == 0, 256 % (C / 8) == 0
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int r = r0 + rr; r < r1; r += rstep) {
-        const size_t e = ((size_t)member * rows + r) * C + c;
-        a += (float)zs[cg_il(e)] + (float)zs[lo_elems + cg_il(e)];
+        const size_t e = cg_il(((size_t)member * rows + r) * C + (size_t)cg * 8);
+        const uint4 h4 = *reinterpret_cast<const uint4*>(zs + e), l4 = *reinterpret_cast<const uint4*>(zs + lo_elems + e);
+        const _Float16* h = reinterpret_cast<const _Float16*>(&h4);
+        const _Float16* l = reinterpret_cast<const _Float16*>(&l4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += (float)h[i] + (float)l[i];
     }
-    __shared__ float red[256];
-    red[threadIdx.x] = a;
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[(rr * tpr + cg) * 8 + i] = a[i];
     __syncthreads();
     if (threadIdx.x < C) {
-        for (int k = 1; k < rstep; ++k) a += red[threadIdx.x + k * C];
-        part[((size_t)member * chunks + chunk) * C + threadIdx.x] = a;
+        float t = 0.f;
+        for (int k = 0; k < rstep; ++k) t += red[k * C + threadIdx.x];      // (k * tpr + c / 8) * 8 + c % 8 = k * C + c
+        part[((size_t)member * chunks + chunk) * C + threadIdx.x] = t;
     }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int C, int chunks,
                                                            const float* __restrict__ scale_dev, float* __restrict__ db,
                                                            long long db_mstride, int accumulate) {
-    const int member = blockIdx.x, c = threadIdx.x;
-    if (c >= C) return;
+    // 256 / C threads per column, each over every (256 / C)-th chunk (independent loads), joined in a fixed order
+    const int member = blockIdx.x, c = threadIdx.x % C, pp = threadIdx.x / C, np = 256 / C;
     float a = 0.f;
-    for (int k = 0; k < chunks; ++k) a += part[((size_t)member * chunks + k) * C + c];
+    for (int k = pp; k < chunks; k += np) a += part[((size_t)member * chunks + k) * C + c];
+    __shared__ float red[256];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x >= C) return;
+    for (int k = 1; k < np; ++k) a += red[k * C + c];
     if (scale_dev) a *= 1.f / scale_dev[0];
     float* o = db + (long long)member * db_mstride + c;
     *o = accumulate ? *o + a : a;
@@ -3050,9 +3063,9 @@ extern "C" int cg_colsum_split(const cg_group* group, const void* zs, size_t lo_
                                int C, float* db, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream) {
     const int n = group ? group->n : 1;
     const long long ms = group ? group->stride : 0;
-    CG_CHECK_ARG(zs && db && ws && C > 0 && C <= 256 && 256 % C == 0 && rows_total > 0 && rows_total % n == 0 &&
+    CG_CHECK_ARG(zs && db && ws && C >= 8 && C <= 256 && 256 % C == 0 && rows_total > 0 && rows_total % n == 0 &&
                      x3_lo_ok(lo_elems, (size_t)rows_total * C * 2),
-                 "cg_colsum_split: bad args (C must divide 256)");
+                 "cg_colsum_split: bad args (C must divide 256 and be a multiple of 8)");
     if (ws_bytes < cg_colsum_split_workspace(C, n)) return cg_set_error(CG_ERR_WORKSPACE, "cg_colsum_split: workspace too small");
     const int rows = (int)(rows_total / n), chunks = 256;
     hipLaunchKernelGGL(colsum_split_kernel, dim3(chunks, n), dim3(256), 0, cg_s(stream), (const _Float16*)zs, (unsigned)lo_elems, rows,

@@ -438,21 +438,44 @@ __global__ void ring_kernel(float* __restrict__ ring_a, float* __restrict__ ring
 // ---- two 1x1 convolutions with nothing between them, composed (MsImageDisCouncil's last two layers, networks.py:142-143:
 //      Conv2d(dim, dim, 1) -> Conv2d(dim, 1, 1), no activation): W2 (W1 y + b1) + b2 = (W2 W1) y + (W2 b1 + b2) -- a dim -> 1
 //      convolution instead of a dim -> dim one.  out (per member, stride S floats): [0, C) = w_eff, [C] = b_eff.
-__global__ __launch_bounds__(256) void compose1x1_fwd_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
+//      Grid (ceil(C / 64) + 1, members), 512 threads: a block owns 64 columns of w_eff, its eight waves each a slice of the j range
+//      (independent loads in flight; a thread per column walking all C rows alone is a chain of C dependent-latency steps: 227 us
+//      at C = 512), partials added in wave order; the last block computes b_eff.  Fixed summation order: deterministic.
+__global__ __launch_bounds__(512) void compose1x1_fwd_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
                                                              const float* __restrict__ W2, const float* __restrict__ b2, int C,
                                                              long long pstride, float* __restrict__ out, int S) {
-    const int m = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     W1 += (long long)m * pstride; b1 += (long long)m * pstride; W2 += (long long)m * pstride; b2 += (long long)m * pstride;
     out += (size_t)m * S;
-    if (k < C) {
+    __shared__ float red[8][64];
+    if (blockIdx.x + 1 < gridDim.x) {
+        const int k = blockIdx.x * 64 + lane;
+        const int per = (C + 7) / 8, j0 = wv * per, j1 = min(C, j0 + per);
         float a = 0.f;
-        for (int j = 0; j < C; ++j) a = fmaf(W2[j], W1[(size_t)j * C + k], a);      // fixed order: deterministic
-        out[k] = a;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float a = b2[0];
-        for (int j = 0; j < C; ++j) a = fmaf(W2[j], b1[j], a);
-        out[C] = a;
+        if (k < C) {
+#pragma unroll 8
+            for (int j = j0; j < j1; ++j) a = fmaf(W2[j], W1[(size_t)j * C + k], a);
+        }
+        red[wv][lane] = a;
+        __syncthreads();
+        if (wv == 0 && k < C) {
+            float t = red[0][lane];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) t += red[w][lane];
+            out[k] = t;
+        }
+    } else {
+        float a = 0.f;
+        for (int j = threadIdx.x; j < C; j += 512) a = fmaf(W2[j], b1[j], a);
+        a = wave_sum(a);
+        if (lane == 0) red[0][wv] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = b2[0];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += red[0][w];
+            out[C] = t;
+        }
     }
 }
 // d (per member, stride S): [0, C) = d w_eff, [C] = d b_eff  ->  dW1[j][k] += W2[j] d w_eff[k];  db1[j] += W2[j] d b_eff;
@@ -544,7 +567,7 @@ extern "C" int cg_compose1x1_fwd(const cg_group* group, const float* W1, const f
                                  float* out, int out_stride, cg_stream_t stream) {
     CG_CHECK_ARG(W1 && b1 && W2 && b2 && out && C > 0 && out_stride > C, "cg_compose1x1_fwd: bad args");
     const int n = group ? group->n : 1;
-    hipLaunchKernelGGL(compose1x1_fwd_kernel, dim3((C + 255) / 256, n), dim3(256), 0, cg_s(stream), W1, b1, W2, b2, C,
+    hipLaunchKernelGGL(compose1x1_fwd_kernel, dim3((C + 63) / 64 + 1, n), dim3(512), 0, cg_s(stream), W1, b1, W2, b2, C,
                        group ? (long long)group->stride : 0, out, out_stride);
     CG_LAUNCH_CHECK("compose1x1_fwd_kernel");
     return CG_OK;

@@ -1216,6 +1216,48 @@ def test_upsample_conv_as_transposed_conv(cga, shape, n):
         assert rel(convs[m].bias._cg_grad, br.grad) < TOL, ("bias gradient", m)
 
 
+@pytest.mark.parametrize("n", [1, 2, 4])
+@pytest.mark.parametrize("C", [64, 512, 96])
+def test_composed_1x1_tail(cga, C, n):
+    """MsImageDisCouncil's last two layers, Conv2d(dim, dim, 1) -> Conv2d(dim, 1, 1) with nothing in between
+    (networks.py:142-143), evaluated as ONE dim -> 1 convolution on w_eff = W2 W1, b_eff = W2 b1 + b2 (cg_compose1x1_fwd / _bwd)
+    against fp64 torch running the two layers: output, data gradient, and the gradients of all four parameters; n members per
+    launch (pool-strided parameters)."""
+    from council_gan_amd import ops
+    from council_gan_amd.optim import ParamPool
+    B, H = 2, 8
+    torch.manual_seed(3 + C + n)
+    nets = [(torch.nn.Conv2d(C, C, 1), torch.nn.Conv2d(C, 1, 1)) for _ in range(n)]
+    for m, (c1, c2) in enumerate(nets):
+        with torch.no_grad():
+            c1.weight.mul_(1.0 + 0.4 * m)
+            c1.bias.normal_(0, 0.3)
+            c2.bias.normal_(0, 0.3)
+    ref = [[p.detach().double().clone() for p in (c1.weight, c1.bias, c2.weight, c2.bias)] for c1, c2 in nets]
+    pool = ParamPool([cga.FlatAdam([p for c in net for p in c.parameters()], lr=1e-4) for net in nets])
+    pool.materialize('cuda')
+    assert ops.composed_tail_ok(*nets[0])
+    y = cl(torch.randn(n * B, C, H, H).cuda())
+    g = cl(torch.randn(n * B, 1, H, H).cuda())
+    yi = y.clone().requires_grad_(True)
+    with ops.members(n):
+        out = ops.composed_tail(yi, *nets[0])
+    out.backward(g)
+    torch.cuda.synchronize()
+    for m in range(n):
+        rows = slice(m * B, (m + 1) * B)
+        yr = y[rows].detach().double().cpu().requires_grad_(True)
+        W1, b1, W2, b2 = [t.clone().requires_grad_(True) for t in ref[m]]
+        o = F.conv2d(F.conv2d(yr, W1, b1), W2, b2)
+        o.backward(g[rows].double().cpu())
+        assert rel(out[rows], o) < TOL, ("forward", m)
+        assert rel(yi.grad[rows], yr.grad) < TOL, ("data gradient", m)
+        c1, c2 = nets[m]
+        for name, got, want in (("dW1", c1.weight._cg_grad, W1.grad), ("db1", c1.bias._cg_grad, b1.grad),
+                                ("dW2", c2.weight._cg_grad, W2.grad), ("db2", c2.bias._cg_grad, b2.grad)):
+            assert rel(got, want) < TOL, (name, m)
+
+
 @pytest.mark.parametrize("n", [1, 2])
 @pytest.mark.parametrize("first", ["thin3", "x3"])
 def test_bounded_split_chain_and_fused_activation_backward(cga, n, first, monkeypatch):
