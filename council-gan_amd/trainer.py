@@ -284,6 +284,9 @@ class Council_Trainer(nn.Module):
         # replicas of a member: all-reduce the decoder's gradient bucket under the encoder's backward (CG_DP_OVERLAP=0: one
         # all-reduce of the whole flat gradient after the backward)
         self._dp_overlap = os.environ.get('CG_DP_OVERLAP', '1') != '0'
+        # gen_update: the discriminator and the council-discriminator branch over x_fake on the two side streams
+        # (CG_GEN_OVERLAP=0: both on the caller's stream)
+        self._gen_overlap = os.environ.get('CG_GEN_OVERLAP', '1') != '0'
         self._hin = HostInputs(dev)
         self._segs, self._recording, self._gx = {}, None, {}
         self._iter_eager, self._phase = True, 0
@@ -1054,8 +1057,32 @@ class Council_Trainer(nn.Module):
                         rg = ring_g[k0 * n_ring:(k0 + g) * n_ring]
                         rc = ring_c[k0 * n_ring:(k0 + g) * n_ring]
                         pd = pos_dev[(d, lead)]
+                        # The adversarial and the council term read the same x_fake through two different discriminators:
+                        # their forward passes go to the two side streams (autograd runs each node's backward on its forward's
+                        # stream, so the backward passes follow), and the HBM-bound passes of one branch -- splits, activation
+                        # backward -- run under the convolutions of the other, as in the two discriminator-side updates.
+                        fork = (self._gen_overlap and bool(self._side) and not self._graph_mode and f['gan_w'] != 0
+                                and f['council_on'])
+                        if fork:
+                            main = torch.cuda.current_stream()
+                            ev = torch.cuda.Event()
+                            ev.record(main)
+                            for st in self._side:
+                                st.wait_event(ev)
+                                x_fake.record_stream(st)
+                            xr.record_stream(self._side[1])
                         if f['gan_w'] != 0:                                           # :498-529
-                            adv = self._nets('dis', d)[lead].calc_gen_loss(x_fake).view(-1)
+                            with (torch.cuda.stream(self._side[0]) if fork else contextlib.nullcontext()):
+                                adv = self._nets('dis', d)[lead].calc_gen_loss(x_fake).view(-1)
+                            if fork:
+                                # same creation order as on one stream (adversarial term first): autograd then adds the two
+                                # branches' gradients of x_fake in the same order, bit for bit
+                                with torch.cuda.stream(self._side[1]):
+                                    lc = self._nets('disc', d)[lead].calc_gen_loss(x_fake, xr).view(-1)
+                                adv.record_stream(main)
+                                lc.record_stream(main)
+                                main.wait_stream(self._side[0])
+                                main.wait_stream(self._side[1])
                             adv_full = self._full_batch(adv)
                             for m, i in enumerate(grp):
                                 out['loss_gen_adv_%s_s' % d][i] = adv_full[m]
@@ -1066,7 +1093,8 @@ class Council_Trainer(nn.Module):
                             roots.append(adv)
                             ups.append(self._const(f['gan_w'], g))
                         if f['council_on']:                                                 # :558-624
-                            lc = self._nets('disc', d)[lead].calc_gen_loss(x_fake, xr).view(-1)
+                            if not fork:
+                                lc = self._nets('disc', d)[lead].calc_gen_loss(x_fake, xr).view(-1)
                             if f['match']:
                                 w_dev = w_all[k0:k0 + g]
                                 check(lib.cg_loss_match_dev(ptr(rg), ptr(rc), n_ring, ptr(pd[1:2]), ptr(self._full_batch(lc)),

@@ -39,6 +39,10 @@ DB=$(find $O/raw -name "*.db" | head -1)
 python $R/tools/rocpd_report.py summary $DB 70 > $O/kernel_stats.txt 2>&1
 python $R/tools/rocpd_report.py timeline $DB 0.4 > $O/timeline.txt 2>&1
 python $R/tools/rocpd_report.py top $DB 60 > $O/top_dispatches.txt 2>&1
+MS=$(grep -o '"ms_per_step": [0-9.]*' $O/bench.json | head -1 | cut -d' ' -f2)
+# the timed steps are the END of the trace only without the kernel-profile leg (BENCH_ARGS=--no-kernel-profile): 80 % of them
+WIN=$(python -c "print(max(2.0, 0.8 * ${STEPS:-3} * ${MS:-0}))")
+python $R/tools/rocpd_report.py alone $DB $WIN ${MS:-0} > $O/alone.txt 2>&1
 rm -rf $O/raw
 head -75 $O/kernel_stats.txt
 cat $O/timeline.txt

@@ -2,6 +2,8 @@
     python tools/rocpd_report.py summary <db> [top=60]          per-kernel calls / total / average / share
     python tools/rocpd_report.py timeline <db> [frac=0.5]       GPU occupancy of the last `frac` of the trace: >= 1 / >= 2 kernels running, idle gaps
     python tools/rocpd_report.py top <db> [n=40] [exclude-regex] the longest individual dispatches that are NOT convolutions
+    python tools/rocpd_report.py alone <db> [frac=0.4 | window ms] [ms_per_step] per kernel: the wall time during which it was the ONLY kernel running
+                                                                (what a multi-stream step actually waits for), idle gaps by predecessor
 """
 import re
 import sqlite3
@@ -94,6 +96,63 @@ def top(path, top=40, excl=r"conv_|head_fwd"):
 
 
 
+def _named_dispatches(c):
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
+    t = next((t for t in tabs if t == "kernels"), None) or next(t for t in tabs if "kernel" in t and "dispatch" in t)
+    cols = [r[1] for r in c.execute("pragma table_info('%s')" % t)]
+    namec = next(cn for cn in ("name", "kernel_name", "kernel") if cn in cols)
+    return c.execute("select %s, start, end from '%s'" % (namec, t)).fetchall()
+
+
+def alone(path, frac=0.4, ms_per_step=0.0):
+    """Sweep over the dispatch intervals of the last `frac` of the trace: time with exactly one kernel running is credited to
+    that kernel, an idle gap to the kernel that ended last before it."""
+    rows = _named_dispatches(sqlite3.connect(path))
+    t0, t1 = min(r[1] for r in rows), max(r[2] for r in rows)
+    lo = t1 - ((t1 - t0) * frac if frac <= 1.0 else frac * 1e6)      # frac > 1: the window in milliseconds
+    ev = []
+    for i, (name, s, e) in enumerate(rows):
+        if e > lo:
+            ev.append((max(s, lo), 1, i))
+            ev.append((e, -1, i))
+    ev.sort(key=lambda x: (x[0], x[1]))
+    running, last, last_ended = set(), lo, None
+    solo, shared, gap, calls = {}, {}, {}, {}
+    short = lambda n: re.sub(r"\(.*", "", re.sub(r"\(anonymous namespace\)::", "", n)).replace("void ", "")[:70]
+    for t, d, i in ev:
+        dt = t - last
+        if dt > 0:
+            if len(running) == 1:
+                k = short(rows[next(iter(running))][0])
+                solo[k] = solo.get(k, 0) + dt
+            elif len(running) > 1:
+                for j in running:
+                    k = short(rows[j][0])
+                    shared[k] = shared.get(k, 0) + dt / len(running)
+            elif last_ended is not None:
+                k = short(rows[last_ended][0])
+                gap[k] = gap.get(k, 0) + dt
+        if d > 0:
+            running.add(i)
+            k = short(rows[i][0])
+            calls[k] = calls.get(k, 0) + 1
+        else:
+            running.discard(i)
+            last_ended = i
+        last = t
+    span = t1 - lo
+    unit = "ms per step (window / %.2f steps of %.3f ms)" % (span / 1e6 / ms_per_step, ms_per_step) if ms_per_step else "ms over the window"
+    print("# last %.1f ms of the trace; alone = only kernel running, shared = its 1/n share of overlapped time," % (span / 1e6))
+    print("# gap = idle time that followed it.  alone + shared + gap over all kernels = the window.  Columns in %s." % unit)
+    names = sorted(set(solo) | set(shared) | set(gap), key=lambda k: -(solo.get(k, 0) + gap.get(k, 0)))
+    sc = (span / ms_per_step) if ms_per_step else 1e6
+    print("%-70s %7s %9s %9s %9s" % ("kernel", "calls", "alone", "shared", "gap"))
+    for k in names[:70]:
+        print("%-70s %7d %9.3f %9.3f %9.3f" % (k, calls.get(k, 0), solo.get(k, 0) / sc, shared.get(k, 0) / sc, gap.get(k, 0) / sc))
+    print("%-70s %7d %9.3f %9.3f %9.3f" % ("TOTAL", sum(calls.values()), sum(solo.values()) / sc, sum(shared.values()) / sc,
+                                           sum(gap.values()) / sc))
+
+
 if __name__ == "__main__":
     cmd, path, rest = sys.argv[1], sys.argv[2], sys.argv[3:]
     if cmd == "summary":
@@ -102,5 +161,7 @@ if __name__ == "__main__":
         timeline(path, float(rest[0]) if rest else 0.5)
     elif cmd == "top":
         top(path, int(rest[0]) if rest else 40, rest[1] if len(rest) > 1 else r"conv_|head_fwd")
+    elif cmd == "alone":
+        alone(path, float(rest[0]) if rest else 0.4, float(rest[1]) if len(rest) > 1 else 0.0)
     else:
         raise SystemExit(__doc__)
