@@ -510,7 +510,10 @@ __global__ __launch_bounds__(512) void conv_fwd_thin_kernel(
 template <int KH, int KW, int CT, int S>
 __global__ __launch_bounds__(512) void conv_wgrad_thin_kernel(
     cg_conv_geom g, const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ dz,
-    float* __restrict__ part, int imgs_per_member, int pad_y, int pad_x, int want_bias) {
+    float* __restrict__ part, int imgs_per_member, int pad_y, int pad_x, int want_bias, const float* __restrict__ yact, int act) {
+    // yact != NULL: `dz` is the gradient of the layer's ACTIVATED output y = act(conv) and yact is that output -- the activation
+    // backward dz = dy * act'(y) happens on the way into LDS (same arithmetic as act_bwd_kernel: bit-identical weight gradients),
+    // so the layers that need no data gradient (the discriminators' first layers) never materialise dz
     constexpr int TH = 16, TW = 16, NT = 512, CO = 64;
     constexpr int K = KH * KW * CT, NKT = (K + 31) / 32;
     constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, PN = PH * PW * CT;
@@ -567,8 +570,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_thin_kernel(
             const int pix = f >> 4, c4 = f & 15;
             const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oy < g.Ho && ox < g.Wo)
-                v = *reinterpret_cast<const float4*>(dz + (((size_t)n * g.Ho + oy) * g.Wo + ox) * CO + c4 * 4);
+            if (oy < g.Ho && ox < g.Wo) {
+                const size_t e = (((size_t)n * g.Ho + oy) * g.Wo + ox) * CO + c4 * 4;
+                v = *reinterpret_cast<const float4*>(dz + e);
+                if (yact) {
+                    const float4 yv = *reinterpret_cast<const float4*>(yact + e);
+                    v.x *= cg_act_grad_from_out(yv.x, act);
+                    v.y *= cg_act_grad_from_out(yv.y, act);
+                    v.z *= cg_act_grad_from_out(yv.z, act);
+                    v.w *= cg_act_grad_from_out(yv.w, act);
+                }
+            }
             dv[j] = v;
         }
     };
@@ -1757,24 +1769,24 @@ static int thin_wgrad_splits(const cg_conv_geom* g, int nmember) {
 
 template <int KH, int KW, int CT, int S>
 int launch_wgrad_thin(const cg_conv_geom* g, const float* x1, const float* x2, const float* dz, float* part, int want_bias,
-                      hipStream_t st, int nmember) {
+                      hipStream_t st, int nmember, const float* yact, int act) {
     const int imgs = g->N / nmember;
     dim3 grid(thin_wgrad_splits(g, nmember), 1, nmember), block(512);
     ProfScope prof(9, 256, 64, true, 2.0 * (double)g->N * g->Ho * g->Wo * 64.0 * (double)(KH * KW * CT), st, g, nmember);
     hipLaunchKernelGGL((conv_wgrad_thin_kernel<KH, KW, CT, S>), grid, block, 0, st, *g, x1, x2, dz, part, imgs, -(int)g->dy[0],
-                       -(int)g->dx[0], want_bias);
+                       -(int)g->dx[0], want_bias, yact, act);
     CG_LAUNCH_CHECK("conv_wgrad_thin_kernel");
     return CG_OK;
 }
 
 int launch_wgrad_thin_variant(int v, const cg_conv_geom* g, const float* x1, const float* x2, const float* dz, float* part,
-                              int want_bias, hipStream_t st, int nmember) {
+                              int want_bias, hipStream_t st, int nmember, const float* yact = nullptr, int act = 0) {
     switch (v) {
-        case 0: return launch_wgrad_thin<7, 7, 3, 1>(g, x1, x2, dz, part, want_bias, st, nmember);
-        case 1: return launch_wgrad_thin<4, 4, 3, 2>(g, x1, x2, dz, part, want_bias, st, nmember);
-        case 2: return launch_wgrad_thin<3, 3, 6, 1>(g, x1, x2, dz, part, want_bias, st, nmember);
-        case 3: return launch_wgrad_thin<3, 3, 3, 1>(g, x1, x2, dz, part, want_bias, st, nmember);
-        case 4: return launch_wgrad_thin<1, 1, 12, 1>(g, x1, x2, dz, part, want_bias, st, nmember);
+        case 0: return launch_wgrad_thin<7, 7, 3, 1>(g, x1, x2, dz, part, want_bias, st, nmember, yact, act);
+        case 1: return launch_wgrad_thin<4, 4, 3, 2>(g, x1, x2, dz, part, want_bias, st, nmember, yact, act);
+        case 2: return launch_wgrad_thin<3, 3, 6, 1>(g, x1, x2, dz, part, want_bias, st, nmember, yact, act);
+        case 3: return launch_wgrad_thin<3, 3, 3, 1>(g, x1, x2, dz, part, want_bias, st, nmember, yact, act);
+        case 4: return launch_wgrad_thin<1, 1, 12, 1>(g, x1, x2, dz, part, want_bias, st, nmember, yact, act);
         default: return cg_set_error(CG_ERR_ARG, "thin weight gradient: no such variant");
     }
 }
@@ -2310,7 +2322,7 @@ extern "C" size_t cg_conv2d_wgrad_workspace_g(const cg_conv_geom* g, const cg_gr
 
 static int conv2d_wgrad_impl(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2, const float* dz,
                              float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream,
-                             const char* who) {
+                             const char* who, const float* yact = nullptr, int act = 0) {
     int rc = validate_geom(g, who);
     if (rc) return rc;
     CG_CHECK_ARG(x1 && dz && dw, "%s: null pointer", who);
@@ -2327,8 +2339,10 @@ static int conv2d_wgrad_impl(const cg_conv_geom* g, const cg_group* group, const
     WgradPlan p = plan_wgrad(g, gr.n);
     float* part = (float*)ws;
     const int want_bias = dbias != nullptr;
+    if (yact && !(wgrad_thin_on() && thin_match(g) >= 0))
+        return cg_set_error(CG_ERR_ARG, "%s: only the thin-input weight gradient folds an activation backward in (cg_conv2d_wgrad_act_ok)", who);
     if (wgrad_thin_on() && thin_match(g) >= 0) {
-        rc = launch_wgrad_thin_variant(thin_match(g), g, x1, x2, dz, part, want_bias, st, gr.n);
+        rc = launch_wgrad_thin_variant(thin_match(g), g, x1, x2, dz, part, want_bias, st, gr.n, yact, act);
         if (rc) return rc;
         return launch_splitk_reduce(part, dw, dbias, (size_t)g->Cout * K, g->Cout, thin_wgrad_splits(g, gr.n), accumulate, gr, st);
     }
@@ -2361,6 +2375,15 @@ extern "C" int cg_conv2d_wgrad_g(const cg_conv_geom* g, const cg_group* group, c
                                  const float* dz, float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes,
                                  cg_stream_t stream) {
     return conv2d_wgrad_impl(g, group, x1, x2, dz, dw, dbias, accumulate, ws, ws_bytes, stream, "cg_conv2d_wgrad_g");
+}
+
+extern "C" int cg_conv2d_wgrad_act_ok(const cg_conv_geom* g) { return g && wgrad_thin_on() && thin_match(g) >= 0; }
+extern "C" int cg_conv2d_wgrad_act_g(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2,
+                                     const float* dy, const float* y, int act, float* dw, float* dbias, int accumulate, void* ws,
+                                     size_t ws_bytes, cg_stream_t stream) {
+    CG_CHECK_ARG(y && (act == CG_ACT_RELU || act == CG_ACT_LRELU || act == CG_ACT_TANH),
+                 "cg_conv2d_wgrad_act_g: needs the activated output and its activation (relu / lrelu / tanh)");
+    return conv2d_wgrad_impl(g, group, x1, x2, dy, dw, dbias, accumulate, ws, ws_bytes, stream, "cg_conv2d_wgrad_act_g", y, act);
 }
 
 // split-precision weight gradient (conv_x3.inc): x and dz arrive as {hi, lo} fp16 planes with their power-of-two

@@ -90,6 +90,8 @@ _SIGS = {
                                      c_size_t, _P]),
     "cg_conv2d_wgrad_workspace_g": (c_size_t, [POINTER(ConvGeom), POINTER(Group)]),
     "cg_conv2d_wgrad_g": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "cg_conv2d_wgrad_act_ok": (c_int, [POINTER(ConvGeom)]),
+    "cg_conv2d_wgrad_act_g": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, _P, _P, _P, c_int, _P, _P, c_int, _P, c_size_t, _P]),
     "cg_conv2d_dgrad_workspace_g": (c_size_t, [POINTER(ConvGeom), POINTER(Group), c_int]),
     "cg_conv2d_dgrad_g": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "cg_lsgan_fwd_g": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),

@@ -297,6 +297,7 @@ class _Conv2d(torch.autograd.Function):
             x = torch.empty_like(x)
             check(lib.cg_unsplit_f16(xs.hi_ptr(), xs.lo, xs.scale_ptr(), ptr(x), x.numel(), stream()), "cg_unsplit_f16")
         dzs = None
+        wgrad_act = None
         applied = act and getattr(dy, "_cg_act_applied", None) == dy._version       # the consumer's data gradient already holds
         if applied:                                                                 # dy * act'(y) in the forms this layer asked for
             dz = dy
@@ -315,6 +316,10 @@ class _Conv2d(torch.autograd.Function):
                 check(lib.cg_unsplit_f16(ys.hi_ptr(), ys.lo, ys.scale_ptr(), ptr(y), y.numel(), stream()), "cg_unsplit_f16")
             if x3_dgrad or x3_wgrad:
                 dz, dzs = act_bwd_split(dy, y, act, fp32_needed, amax)  # no fp32 round trip of dz when nobody reads it
+            elif WGRAD_ACT and need_dw and not need_dx and bool(lib.cg_conv2d_wgrad_act_ok(byref(g))):
+                # only the weight gradient reads dz, and this layer's kernel applies act'(y) while it loads dy (the
+                # discriminators' first layers in their own updates): dz is never written
+                dz, wgrad_act = dy, (y, act)
             else:
                 dz = torch.empty_like(dy)
                 check(lib.cg_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), act, stream()), "cg_act_bwd")
@@ -374,6 +379,10 @@ class _Conv2d(torch.autograd.Function):
                                                    dzs.scale_ptr(), ptr(dw_t), ptr(db_t), acc, ptr(ws), ws.numel(), stream()),
                           "cg_conv2d_wgrad_x3")
                     used = (xs.buf, xs.state, dzs.buf, dzs.state)
+                elif wgrad_act is not None:
+                    check(lib.cg_conv2d_wgrad_act_g(byref(g), grp, ptr(x), ptr(x2), ptr(dz), ptr(wgrad_act[0]), wgrad_act[1],
+                                                    ptr(dw_t), ptr(db_t), acc, ptr(ws), ws.numel(), stream()), "cg_conv2d_wgrad_act")
+                    used = (x, x2, dz, wgrad_act[0])
                 else:
                     check(lib.cg_conv2d_wgrad_g(byref(g), grp, ptr(x), ptr(x2), ptr(dz), ptr(dw_t), ptr(db_t), acc, ptr(ws),
                                                 ws.numel(), stream()), "cg_conv2d_wgrad")
@@ -396,6 +405,8 @@ class _Conv2d(torch.autograd.Function):
 # against 71.7 ms without (the weight-gradient kernels are MFMA-bound like the data-gradient kernels they then compete with,
 # and the batched elementwise passes are too short to hide them) -- so it is OFF unless CG_WGRAD_STREAM=1.
 WGRAD_STREAM = os.environ.get("CG_WGRAD_STREAM", "0") == "1"
+# CG_WGRAD_ACT=0: the thin-input layers run their activation backward as a pass of its own before the weight gradient
+WGRAD_ACT = os.environ.get("CG_WGRAD_ACT", "1") != "0"
 # CG_WGRAD_AFTER_DGRAD=1 (with CG_WGRAD_STREAM=1): the companion stream waits for the layer's data gradient, not just for dz
 WGRAD_AFTER_DGRAD = os.environ.get("CG_WGRAD_AFTER_DGRAD", "1") == "1"
 _companions = {}

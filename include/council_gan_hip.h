@@ -276,6 +276,15 @@ int cg_conv2d_wgrad(const cg_conv_geom* g, const float* x1, const float* x2, con
 size_t cg_conv2d_wgrad_workspace_g(const cg_conv_geom* g, const cg_group* group);
 int cg_conv2d_wgrad_g(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2, const float* dz,
                       float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, cg_stream_t stream);
+/* the same for a layer whose data gradient nobody needs (the discriminators' first layers in dis_update / dis_council_update,
+ * trainer_council.py:779,882: the input is an image): dy is the gradient of the ACTIVATED output y = act(conv(x)) and the
+ * activation backward dz = dy * act'(y) (networks.py:44-47, the LeakyReLU behind the first Conv2dBlock) happens while the
+ * kernel loads dz -- no pass that writes dz.  Only the thin-input layers (<= 12 input channels, 64 outputs) take it:
+ * cg_conv2d_wgrad_act_ok says whether g does; other geometries are refused.  Bit-identical to cg_act_bwd + cg_conv2d_wgrad_g. */
+int cg_conv2d_wgrad_act_ok(const cg_conv_geom* g);
+int cg_conv2d_wgrad_act_g(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2, const float* dy,
+                          const float* y, int act, float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                          cg_stream_t stream);
 
 /* dx (w.r.t. input channels [ci0, ci0+nci) of the convolution described by the FORWARD geometry g) from
  * dz [N, Ho, Wo, Cout]; dx is the dense [N, H<<up, W<<up, nci] tensor at the resolution the taps see (a nearest-2x

@@ -600,6 +600,35 @@ def test_thin_input_weight_gradient(cga, case):
                 assert rel(got[0], rw) < 5e-6 and rel(got[1], rb) < 5e-6, (n, m, rel(got[0], rw), rel(got[1], rb))
     rw, rb = ref(0, N)
     assert rel(thin_acc[0][0], rw) < 2e-5 and rel(thin_acc[0][1], rb) < 2e-5     # (0.5 + g) - 0.5 in fp32
+    # the activation backward folded into the kernel's dz load (cg_conv2d_wgrad_act_g: the discriminators' first layers in their
+    # own updates need no data gradient) against cg_act_bwd + cg_conv2d_wgrad_g: the same bits, for lrelu and relu
+    assert lib.cg_conv2d_wgrad_act_ok(byref(geom)) == 1
+    yd = cl(dev(torch.randn(N, 64, Ho, Wo, generator=g, dtype=torch.float64)))
+    for act in (ops.ACT["lrelu"], ops.ACT["relu"]):
+        for nmember in members:
+            stride_el = nw + 64 + 32
+            grp = hip.Group(nmember, 0, stride_el)
+            wsb = hip.workspace(lib.cg_conv2d_wgrad_workspace_g(byref(geom), byref(grp)))
+            dz = torch.empty_like(gyd)
+            hip.check(lib.cg_act_bwd(hip.ptr(gyd), hip.ptr(yd), hip.ptr(dz), dz.numel(), act, hip.stream()), "act_bwd")
+            two = torch.full((nmember * stride_el,), float("nan"), device="cuda")
+            hip.check(lib.cg_conv2d_wgrad_g(byref(geom), byref(grp), hip.ptr(x1d), hip.ptr(x2d), hip.ptr(dz), hip.ptr(two[:nw]),
+                                            hip.ptr(two[nw:]), 0, hip.ptr(wsb), wsb.numel(), hip.stream()), "wgrad_g")
+            one = torch.full((nmember * stride_el,), float("nan"), device="cuda")
+            hip.check(lib.cg_conv2d_wgrad_act_g(byref(geom), byref(grp), hip.ptr(x1d), hip.ptr(x2d), hip.ptr(gyd), hip.ptr(yd), act,
+                                                hip.ptr(one[:nw]), hip.ptr(one[nw:]), 0, hip.ptr(wsb), wsb.numel(), hip.stream()),
+                      "wgrad_act_g")
+            torch.cuda.synchronize()
+            for m in range(nmember):
+                a, b = one[m * stride_el:m * stride_el + nw + 64], two[m * stride_el:m * stride_el + nw + 64]
+                assert torch.equal(a, b), (act, nmember, m, float((a - b).abs().max()))
+    wide = ops.fwd_geom(2, 16, 16, 64, 0, 0, 3, 3, 1, 1, 64, 0)          # not a thin-input layer: refused, not mis-computed
+    assert lib.cg_conv2d_wgrad_act_ok(byref(wide)) == 0
+    xw, gw = cl(torch.randn(2, 64, 16, 16).cuda()), cl(torch.randn(2, 64, 16, 16).cuda())
+    out = torch.empty(64 * 64 * 9 + 64, device="cuda")
+    wsb = hip.workspace(lib.cg_conv2d_wgrad_workspace_g(byref(wide), None))
+    assert lib.cg_conv2d_wgrad_act_g(byref(wide), None, hip.ptr(xw), None, hip.ptr(gw), hip.ptr(gw), ops.ACT["relu"], hip.ptr(out),
+                                     None, 0, hip.ptr(wsb), wsb.numel(), hip.stream()) != 0
 
 
 # ------------------------------------------------------------------------------------------
