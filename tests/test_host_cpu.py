@@ -387,6 +387,35 @@ def test_tool_helpers_on_host(tmp_path):
     assert n.shape == (4, 4, 3) and n.min() == 0 and n.max() == 255
 
 
+def test_exclusive_time_report_on_a_synthetic_trace(tmp_path, capsys):
+    """tools/rocpd_report.py alone: time with exactly one kernel running goes to that kernel, overlapped time is shared 1/n, an idle
+    gap goes to the kernel that ended before it -- and the three columns add up to the window."""
+    import sqlite3
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import rocpd_report as R
+    db = str(tmp_path / "t.db")
+    c = sqlite3.connect(db)
+    c.execute("create table kernels(name text, start int, end int)")
+    # ns:  a [0, 1000)   b [500, 1500)   (idle 1500-2000)   c [2000, 2500)   a [2500, 3000)
+    c.executemany("insert into kernels values (?, ?, ?)",
+                  [("void (anonymous namespace)::a<1, 2>(float*)", 0, 1000), ("b(int)", 500, 1500), ("c", 2000, 2500),
+                   ("void (anonymous namespace)::a<1, 2>(float*)", 2500, 3000)])
+    c.commit()
+    c.close()
+    R.alone(db, 1.0)
+    out = capsys.readouterr().out
+    rows = {}
+    for line in out.splitlines():
+        f = line.split()
+        if len(f) >= 5 and f[0] in ("a<1,", "b", "c", "TOTAL"):
+            rows[f[0]] = [float(v) for v in f[-3:]] + [int(f[-4])]
+    assert rows["a<1,"][:3] == [0.001, 0.0, 0.0] and rows["a<1,"][3] == 2          # 500 + 500 ns alone, 250 ns shared (rounds to 0.000)
+    assert rows["b"][0] == 0.001 and rows["b"][2] == 0.001                          # 500 ns alone, the 500 ns gap follows it
+    assert rows["c"][0] == 0.001
+    assert abs(sum(rows["TOTAL"][:3]) - 0.003) < 1.1e-3                            # = the 3000 ns window (three-decimal ms columns)
+
+
 @pytest.mark.parametrize("n", [2, 8])
 def test_bench_starts_its_own_ranks(n):
     """`python bench.py --gpus N` with no launcher around it must start N ranks itself (torch.distributed.run, rendezvous on
