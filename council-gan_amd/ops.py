@@ -999,6 +999,7 @@ class SplitWeights:
         self.state = None
         self.views = {}
         self._dgrad = {}
+        self._plan = {}
         # frozen: the mirror was refreshed at the start of an update (Council_Trainer._fresh_mirrors) and must not be
         # re-split inside it -- with several member groups on several streams, one group's Adam step moves the pool's
         # version while another group is still reading ITS members' (unchanged) slices of the mirror
@@ -1051,13 +1052,39 @@ class SplitWeights:
         key = (id(weight), ci0, nci, n)
         wt = self._dgrad.get(key)
         if wt is None:
-            lib = _lib()
-            elems = lib.cg_conv2d_dgrad_x3_wt_elems(byref(g), nci)
-            wt = torch.empty(2 * n * elems, dtype=torch.float16, device=w.device)
-            check(lib.cg_conv2d_dgrad_x3_prep(byref(g), grp, ptr(w), ci0, nci, 1.0, self.scale_ptr(), ptr(wt),
-                                              wt.numel() * 2, stream()), "cg_conv2d_dgrad_x3_prep")
-            self._dgrad[key] = wt
+            wt = self._dgrad_build(key, weight, w, g, ci0, nci, grp, n)
+            self._plan[key] = (weight, g, ci0, nci, grp, n)       # what prefetch_dgrad prepares for the next weight version
         return wt
+
+    def _dgrad_build(self, key, weight, w, g, ci0, nci, grp, n, on=None):
+        """One cg_conv2d_dgrad_x3_prep launch (on stream `on`, default the current one); the buffer is allocated on the CURRENT
+        stream either way -- that is where it is read."""
+        lib = _lib()
+        elems = lib.cg_conv2d_dgrad_x3_wt_elems(byref(g), nci)
+        wt = torch.empty(2 * n * elems, dtype=torch.float16, device=w.device)
+        check(lib.cg_conv2d_dgrad_x3_prep(byref(g), grp, ptr(w), ci0, nci, 1.0, self.scale_ptr(), ptr(wt), wt.numel() * 2,
+                                          c_void_p(on.cuda_stream) if on is not None else stream()), "cg_conv2d_dgrad_x3_prep")
+        self._dgrad[key] = wt
+        return wt
+
+    def prefetch_dgrad(self, side):
+        """Prepare, on stream `side`, the data-gradient weights of every layer that asked for them under the previous weight
+        version and has none for the current one.  These are 5 us launches, one per layer and version, that otherwise sit in the
+        chain of the backward pass (44 per benchmark step, 62 on a rank with one member); issued at the start of the update they
+        run beside the forward pass.  The caller orders `side` behind the current stream first (the weights' scale is written by
+        refresh()) and makes the backward wait for the event it records on `side` afterwards.  Returns the number of launches."""
+        if not self._plan or not self.refresh():
+            return 0
+        n_built = 0
+        for key, (weight, g, ci0, nci, grp, n) in list(self._plan.items()):
+            if key in self._dgrad:
+                continue
+            if id(weight) not in self.views:
+                del self._plan[key]
+                continue
+            self._dgrad_build(key, weight, nhwc(weight), g, ci0, nci, grp, n, on=side)
+            n_built += 1
+        return n_built
 
     def l1_bound(self, weight, bias, grp, n, by_ci):
         """Device float[2] {largest row (by_ci = False) / column (True) 1-norm of `weight` over the members of the scope, largest
