@@ -358,6 +358,52 @@ def test_split_tensor_layout_bookkeeping(interleaved, monkeypatch):
             ops.SplitTensor(buf, (n,), off=8).hi_ptr()          # sub-tensors start on 32-element boundaries
 
 
+def test_dgrad_mirror_prefetch_bookkeeping(monkeypatch):
+    """ops.SplitWeights.prefetch_dgrad (gen_update's start): the layers that asked for data-gradient weights under the previous
+    weight version are prepared again for the new one -- each once, on the given stream, only those without a current entry --
+    and a lazy request afterwards finds them.  The library is replaced by a recorder: host bookkeeping only."""
+    import types
+    from council_gan_amd import hip, ops
+
+    calls = []
+
+    class Lib:
+        def cg_split_f16_dynamic_capped(self, *a):
+            calls.append(("split", a[-1].value))
+            return 0
+
+        def cg_conv2d_dgrad_x3_wt_elems(self, g, nci):
+            return 64 * nci
+
+        def cg_conv2d_dgrad_x3_prep(self, *a):
+            calls.append(("prep", a[-1].value))
+            return 0
+
+    monkeypatch.setattr(ops, "_lib", lambda: Lib())
+    monkeypatch.setattr(ops, "_X3_IL", True)
+    monkeypatch.setattr(ops, "stream", lambda: ops.c_void_p(111))
+    monkeypatch.setattr(ops, "ptr", lambda t: None if t is None else ops.c_void_p(t.data_ptr()))     # (the real one refuses host tensors)
+    w1, w2 = torch.nn.Parameter(torch.zeros(64, 32, 3, 3)), torch.nn.Parameter(torch.zeros(32, 32, 1, 1))
+    owner = types.SimpleNamespace(version=0, _flat=True, _params=[w1, w2],
+                                  flat={'data': torch.zeros(w1.numel() + w2.numel()), 'offs': [0, w1.numel()]})
+    mgr = ops.SplitWeights(owner)
+    side = types.SimpleNamespace(cuda_stream=222)
+    g = hip.ConvGeom()
+    assert mgr.prefetch_dgrad(side) == 0 and not calls                      # nothing was ever asked for: nothing to prepare
+    a = mgr.dgrad_weights(w1, w1, g, 0, 32, None, 1)                        # lazy request: built on the current stream, planned
+    assert [c for c in calls if c[0] == "prep"] == [("prep", 111)] and a is mgr.dgrad_weights(w1, w1, g, 0, 32, None, 1)
+    b = mgr.dgrad_weights(w2, w2, g, 0, 32, None, 1)
+    assert mgr.prefetch_dgrad(side) == 0                                    # both entries are current
+    owner.version = 1                                                       # an optimizer step
+    calls.clear()
+    assert mgr.prefetch_dgrad(side) == 2
+    assert [c for c in calls if c[0] == "prep"] == [("prep", 222)] * 2 and calls[0] == ("split", 111)      # mirror first, own stream
+    calls.clear()
+    a2 = mgr.dgrad_weights(w1, w1, g, 0, 32, None, 1)                       # the backward finds them: no launch
+    assert not calls and a2 is not a and a2.numel() == a.numel() and b.numel() == 2 * 64 * 32
+    assert mgr.prefetch_dgrad(side) == 0
+
+
 def test_tool_helpers_on_host(tmp_path):
     """The host-only helpers of tools/translate_folder.py and tools/train_synthetic.py (image loading geometry, strip layout)."""
     import sys
