@@ -113,6 +113,17 @@ def _dp_worker(rank, world, port, council, q):
         shard.replica_mean_(g)
         base = (rank // dp) * dp
         assert torch.equal(g, torch.full((5,), sum(range(base, base + dp)) / dp))
+        # the bucket form trainer._gen_body uses for the decoder's share of the flat gradient (replica_mean_begin under the
+        # encoder's backward, replica_mean_end before the optimizer step): a VIEW of the flat buffer is averaged in place; on
+        # every transport but RCCL the mean is complete at begin and there is nothing to wait for
+        flat = torch.arange(12, dtype=torch.float32) + 100.0 * rank
+        h = shard.replica_mean_begin(flat[4:9])
+        assert h is None
+        shard.replica_mean_end(h)
+        mean_rank = sum(range(base, base + dp)) / dp
+        want = torch.arange(12, dtype=torch.float32) + 100.0 * rank
+        want[4:9] = torch.arange(4, 9, dtype=torch.float32) + 100.0 * mean_rank
+        assert torch.equal(flat, want), (rank, flat)
         # logging: a member's value is the mean of its replicas' batch-slice values
         vals = [-1.0] * council
         vals[rank // dp] = 10.0 * (rank // dp) + (rank % dp)
