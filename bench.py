@@ -189,10 +189,12 @@ def build_config(args, world):
     return cfg
 
 
-def cpu_baseline(cfg, tr_state_fn, size, batch_full, timed=1):
+def cpu_baseline(cfg, tr_state_fn, size, batch_full, timed=2):
     """Oracle ("port" of the reference) on the host cores, bounded sample: the same council / resolution at batch_size 1,
-    one warm-up iteration + `timed` timed ones.  One timed iteration (about 30 s on the GPU box's host): the leg
-    used to be 125 of the run's 135 seconds, which is what the driver's GPU-busy sampling then mostly saw."""
+    one warm-up iteration + `timed` timed ones, the FASTER of which is reported together with both samples.
+    The iteration's cost is linear in the batch (every operator is per sample; measured 27.9 s at batch 1), so images/sec at
+    batch 1 is the per-image rate the batch-4 GPU line is to be read against; timing batch 4 itself would be ~2 minutes per
+    iteration of a run that must finish within minutes."""
     from oracle import council_oracle as O
     cfg = copy.deepcopy(cfg)
     cfg['batch_size'] = 1
@@ -207,15 +209,20 @@ def cpu_baseline(cfg, tr_state_fn, size, batch_full, timed=1):
     t0 = time.time()
     it()
     warm = time.time() - t0
-    t0 = time.time()
+    samples = []
     for _ in range(timed):
+        t0 = time.time()
         it()
-    dt = (time.time() - t0) / timed
+        samples.append(time.time() - t0)
+    dt = min(samples)
     return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/council_oracle.py at batch_size 1 (the GPU line runs batch_size %d): the same %dx%d council=%d "
-                      "iteration (dis + dis_council + gen updates of all members), 1 warm-up (%.1f s) + %d timed iterations, "
-                      "%.1f s each, %d torch threads"
-                      % (batch_full, size, size, cfg['council']['council_size'], warm, timed, dt, torch.get_num_threads())}
+            "seconds_per_iteration": [round(v, 2) for v in samples],
+            "sample": "oracle/council_oracle.py at batch_size 1 (the GPU line runs batch_size %d; the iteration is per-sample work, "
+                      "so images/sec at batch 1 is the per-image rate to compare with): the same %dx%d council=%d iteration (dis + "
+                      "dis_council + gen updates of all members), 1 warm-up (%.1f s) + %d timed iterations (%s s), fastest reported, "
+                      "%d torch threads"
+                      % (batch_full, size, size, cfg['council']['council_size'], warm, timed,
+                         ", ".join("%.1f" % v for v in samples), torch.get_num_threads())}
 
 
 def time_steps(step, fence, warmup, steps, first=0, own=None):
@@ -302,6 +309,9 @@ def kernel_profile(cga, trainer, run_one):
     overlap, trainer._overlap = trainer._overlap, False
     graph_mode, trainer._graph_mode = trainer._graph_mode, False
     wstream, cga.ops.WGRAD_STREAM = cga.ops.WGRAD_STREAM, False
+    # gen_update's two-branch fork keys on the side-stream list, its weight-mirror prefetch on its own switch: both off too
+    side, trainer._side = trainer._side, []
+    prefetch, trainer._dgrad_prefetch = trainer._dgrad_prefetch, False
     try:
         cga.hip.prof_enable(True)
         run_one()
@@ -313,6 +323,7 @@ def kernel_profile(cga, trainer, run_one):
         cga.hip.prof_enable(False)
         trainer._streams, trainer._overlap, cga.ops.WGRAD_STREAM = streams, overlap, wstream
         trainer._graph_mode = graph_mode
+        trainer._side, trainer._dgrad_prefetch = side, prefetch
 
 
 def dominant_kernel(prof):

@@ -66,3 +66,6 @@ class Segment:
         self.out = None
         self.effects = []
         self.generation = -1
+        self.serial = 0           # capture number (trainer-wide) of the current graph
+        self.parents = {}         # kind -> serial of the earlier segments of the iteration this graph was captured behind
+        self.used = 0             # trainer-wide use clock (least recently used segment of a kind is evicted first)

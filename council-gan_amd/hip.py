@@ -258,6 +258,30 @@ def workspace(nbytes, slot=0):
     return buf
 
 
+_const_stream = {}
+
+
+def upload_const(host):
+    """Device copy of a small host tensor that is about to enter a BY-VALUE cache read from several HIP streams (gather
+    index vectors, LSGAN target / weight vectors).  A `non_blocking` copy on the stream that happens to miss first is not
+    enough there: a second stream hitting the cache a moment later has no ordering against that copy and its kernel reads
+    whatever the fresh allocation held -- garbage row indices, i.e. an out-of-bounds gather (the intermittent memory fault
+    of round 4's driver run).  So the copy goes to a dedicated stream and the HOST waits for it (a few microseconds: that
+    stream carries nothing else), after which the tensor is valid for every stream.  Not possible while the current
+    stream is being captured into a hipGraph: the warm-up pass has filled the caches by then, and a miss there raises
+    (Council_Trainer._run then falls back to eager execution)."""
+    if torch.cuda.is_current_stream_capturing():
+        raise HipError("upload_const: cache miss inside a hipGraph capture (the eager warm-up pass did not see this value)")
+    dev = torch.cuda.current_device()
+    st = _const_stream.get(dev)
+    if st is None:
+        st = _const_stream[dev] = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        out = host.pin_memory().to("cuda:%d" % dev, non_blocking=True)
+    st.synchronize()
+    return out
+
+
 def tuning():
     """Current kernel-selection table (cg_tuning_get)."""
     t = Tuning()

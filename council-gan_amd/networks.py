@@ -318,8 +318,7 @@ class Decoder_V2_atten(nn.Module):
             blk = self.model[i + 1]
             wmgr = getattr(blk, '_cg_wmgr', None)
             w = blk.conv.weight
-            if wmgr is not None and ops.UPCONV and ops.X3_FORWARD and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 \
-                    and getattr(w, '_cg_grad', None) is not None and tuple(w.shape[2:]) == (3, 3):
+            if ops.upconv_weight_ok(w, wmgr):
                 wmgr.upconv_weights(w, ops._grp(w), ops.group_n())
             i += 3
 
@@ -460,11 +459,8 @@ class _LossVectors:
         key = (tuple(tgt), tuple(wt), str(device))
         v = self._cache.get(key)
         if v is None:
-            h = (torch.tensor(tgt, dtype=torch.float32).pin_memory(), torch.tensor(wt, dtype=torch.float32).pin_memory())
-            v = (h[0].to(device, non_blocking=True), h[1].to(device, non_blocking=True))     # no host stall on a miss
-            v[0]._cg_host = h
-            if len(self._cache) > 256:
-                self._cache.clear()
+            # published only once the copies have completed: the module is called from more than one stream (hip.upload_const)
+            v = (hip.upload_const(torch.tensor(tgt, dtype=torch.float32)), hip.upload_const(torch.tensor(wt, dtype=torch.float32)))
             self._cache[key] = v
         return v
 

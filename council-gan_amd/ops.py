@@ -542,12 +542,17 @@ class _UpConv2d(torch.autograd.Function):
 _upc_ok_cache = {}
 
 
+def upconv_weight_ok(weight, wmgr):
+    """The shape-independent half of _upconv_ok: could a layer with this weight take the summed-tap path at all?  Also the
+    predicate of Decoder.prepare_split_weights, so that preparation and use cannot diverge."""
+    return bool(UPCONV and X3_FORWARD and X3_BACKWARD and wmgr is not None and weight.dim() == 4
+                and tuple(weight.shape[2:]) == (3, 3) and weight.shape[0] % 32 == 0 and weight.shape[1] % 32 == 0
+                and 256 % weight.shape[0] == 0 and getattr(weight, "_cg_grad", None) is not None and x3_interleaved())
+
+
 def _upconv_ok(shape, weight, stride, pad, act, x2, wmgr):
     """Does this upsample + convolution layer take the summed-tap path?  `shape` = (N, Cin, H, W) of the source."""
-    if not (UPCONV and X3_FORWARD and X3_BACKWARD and wmgr is not None and x2 is None and weight.dim() == 4
-            and tuple(weight.shape[2:]) == (3, 3) and stride == 1 and pad == 1 and ACT[act] == 0
-            and weight.shape[0] % 32 == 0 and weight.shape[1] % 32 == 0 and 256 % weight.shape[0] == 0
-            and getattr(weight, "_cg_grad", None) is not None and x3_interleaved()):
+    if not (upconv_weight_ok(weight, wmgr) and x2 is None and stride == 1 and pad == 1 and ACT[act] == 0):
         return False
     N, Cin, H, W = shape
     Cout, n = weight.shape[0], _G.n
@@ -885,22 +890,36 @@ def activation(x, act):
 
 
 class _LayerNorm(torch.autograd.Function):
-    """networks.py:670-686."""
+    """networks.py:670-686.  Under ops.members(n) the batch holds the n members' samples member-major and every member has
+    its OWN gamma / beta (`stride` fp32 elements apart in the optimizer pool, like every other parameter): one launch per
+    member on its rows -- LayerNorm is in no shipped configuration, so it stays a plain per-member loop."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
         lib = _lib()
         x = nhwc(x)
         N, C, H, W = x.shape
+        n = max(1, _G.n)
+        stride = 0
+        if n > 1:
+            pool = getattr(gamma, '_cg_pool', None)
+            if pool is None or getattr(beta, '_cg_pool', None) is not pool or N % n:
+                raise hip.HipError("member-batched LayerNorm: gamma / beta must live in one optim.ParamPool and the batch "
+                                   "must hold the members' samples member-major")
+            stride = pool.stride
         ctx.bufs = (getattr(gamma, "_cg_grad", None), getattr(beta, "_cg_grad", None))
         y = torch.empty_like(x)
         mean = torch.empty(N, dtype=torch.float32, device=x.device)
         std = torch.empty_like(mean)
-        ws = workspace(lib.cg_layernorm_workspace(N, H * W, C))
-        check(lib.cg_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(std), N, H * W, C, eps, ptr(ws),
-                                   ws.numel(), stream()), "cg_layernorm_fwd")
+        b = N // n
+        ws = workspace(lib.cg_layernorm_workspace(b, H * W, C))
+        row = C * H * W
+        for m in range(n):
+            check(lib.cg_layernorm_fwd(_off(x, m * b * row), _off(gamma, m * stride), _off(beta, m * stride), _off(y, m * b * row),
+                                       _off(mean, m * b), _off(std, m * b), b, H * W, C, eps, ptr(ws), ws.numel(), stream()),
+                  "cg_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, std)
-        ctx.eps = eps
+        ctx.eps, ctx.n, ctx.stride = eps, n, stride
         return y
 
     @staticmethod
@@ -909,18 +928,25 @@ class _LayerNorm(torch.autograd.Function):
         x, gamma, mean, std = ctx.saved_tensors
         dy = nhwc(dy)
         N, C, H, W = x.shape
+        n, stride = ctx.n, ctx.stride
+        b, row = N // n, C * H * W
         dx = torch.empty_like(x)
-        dg = torch.empty_like(gamma)
-        db = torch.empty_like(gamma)
-        ws = workspace(lib.cg_layernorm_workspace(N, H * W, C))
-        check(lib.cg_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(std), ptr(dx), ptr(dg), ptr(db), N, H * W,
-                                   C, ctx.eps, ptr(ws), ws.numel(), stream()), "cg_layernorm_bwd")
+        dg = torch.empty(n * C, dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dg)
+        ws = workspace(lib.cg_layernorm_workspace(b, H * W, C))
         gbuf, bbuf = ctx.bufs
+        if n > 1 and (gbuf is None or bbuf is None):
+            raise hip.HipError("member-batched LayerNorm backward needs the pool's gradient buffers")
+        for m in range(n):
+            check(lib.cg_layernorm_bwd(_off(dy, m * b * row), _off(x, m * b * row), _off(gamma, m * stride), _off(mean, m * b),
+                                       _off(std, m * b), _off(dx, m * b * row), _off(dg, m * C), _off(db, m * C), b, H * W, C,
+                                       ctx.eps, ptr(ws), ws.numel(), stream()), "cg_layernorm_bwd")
+            if gbuf is not None and bbuf is not None:
+                check(lib.cg_axpby(1.0, _off(dg, m * C), 1.0, _off(gbuf, m * stride), C, stream()), "cg_axpby")
+                check(lib.cg_axpby(1.0, _off(db, m * C), 1.0, _off(bbuf, m * stride), C, stream()), "cg_axpby")
         if gbuf is not None and bbuf is not None:
-            check(lib.cg_axpby(1.0, ptr(dg), 1.0, ptr(gbuf), C, stream()), "cg_axpby")
-            check(lib.cg_axpby(1.0, ptr(db), 1.0, ptr(bbuf), C, stream()), "cg_axpby")
             gbuf._cg_touched = bbuf._cg_touched = True
-            dg = db = None
+            return dx, None, None, None
         return dx, dg, db, None
 
 
@@ -1549,13 +1575,9 @@ def _index_tensor(idx, device):
     key = (tuple(idx), str(device))
     t = _idx_cache.get(key)
     if t is None:
-        if len(_idx_cache) > 512:
-            _idx_cache.clear()
-        # through pinned memory: a pageable-memory upload blocks the host until the stream has drained (8 ms per miss
-        # inside a training step)
-        h = torch.tensor(list(idx), dtype=torch.int32).pin_memory()
-        t = _idx_cache[key] = h.to(device, non_blocking=True)
-        t._cg_host = h                 # keeps the pinned source alive until the copy has certainly run
+        # entries are never dropped: captured hipGraphs hold the addresses (a few hundred bytes per distinct shape plan).
+        # The upload completes before the tensor is published -- the cache is read from every stream (hip.upload_const)
+        t = _idx_cache[key] = hip.upload_const(torch.tensor(list(idx), dtype=torch.int32))
     return t
 
 

@@ -293,6 +293,7 @@ class Council_Trainer(nn.Module):
         self._prep_stream = torch.cuda.Stream(device=dev)
         self._hin = HostInputs(dev)
         self._segs, self._recording, self._gx = {}, None, {}
+        self._iter_serials = {}
         self._iter_eager, self._phase = True, 0
         self._overlap = os.environ.get('CG_OVERLAP_UPDATES', '0' if (self.shard.dp > 1 or self._graph_mode) else '1') != '0'
         if self._graph_mode and self._overlap:
@@ -526,14 +527,28 @@ class Council_Trainer(nn.Module):
             # call order), the rest of that iteration runs eagerly too (self._iter_eager, reset by dis_update).
             seg = self._segs.get(key)
             if seg is None:
-                # a new (shapes, schedule flags, hyper-parameters) key of this kind replaces the old one: its graph and the
-                # activation pool the graph owns are released instead of staying resident next to the new capture
-                for k in [k for k in self._segs if k[0] == key[0]]:
-                    old = self._segs.pop(k)
-                    old.graph, old.out, old.effects = None, None, []
+                # a new (shapes, schedule flags, hyper-parameters) key of this kind: at most CG_GRAPH_KEEP (default 2) segments
+                # per kind stay resident (schedule flags that alternate -- council.flipOnOff -- then flip between two captures
+                # instead of re-capturing at every flip); beyond that the least recently used one and the activation pool its
+                # graph owns are released -- after the device has drained, no replay of it may still be in flight
+                same = sorted((k for k in self._segs if k[0] == key[0]), key=lambda k: self._segs[k].used)
+                keep = max(1, int(os.environ.get('CG_GRAPH_KEEP', '2')))
+                if len(same) >= keep:
+                    torch.cuda.synchronize(self._device)
+                    for k in same[:len(same) - keep + 1]:
+                        old = self._segs.pop(k)
+                        old.graph, old.out, old.effects = None, None, []
                 seg = self._segs[key] = Segment()
             if seg.graph is not None and seg.generation != self._hin.generation:
                 seg.graph, seg.warm = None, 0                      # a static input buffer moved: capture again
+            if seg.graph is not None and seg.parents != self._iter_serials:
+                # the earlier segments of THIS iteration are not the captures this graph was recorded behind (one of them was
+                # re-captured or evicted since): the tensors it reads from their pools -- content codes, the repeated batch, the
+                # translations -- have moved.  Its warm-up has happened; capture again, behind the current ones.
+                torch.cuda.synchronize(self._device)
+                seg.graph, seg.out, seg.effects = None, None, []
+            self._seg_clock = self.__dict__.get('_seg_clock', 0) + 1
+            seg.used = self._seg_clock
             if self._iter_eager or (seg.graph is None and seg.warm < self._graph_warmup):
                 seg.warm += 1
                 self._iter_eager = True
@@ -584,7 +599,9 @@ class Council_Trainer(nn.Module):
                         return
                     seg.graph, seg.generation = g, self._hin.generation
                     self._n_captures = self.__dict__.get('_n_captures', 0) + 1
+                    seg.serial, seg.parents = self._n_captures, dict(self._iter_serials)
                 seg.graph.replay()
+                self._iter_serials[key[0]] = seg.serial
                 for fn in seg.effects:
                     fn()
                 out = seg.out
@@ -695,8 +712,10 @@ class Council_Trainer(nn.Module):
         pool = self._pools['gen']
         gen = self._nets('gen', d)[i]
         dec, mlp = list(gen.dec.parameters()), list(gen.mlp.parameters())
-        k, pi = pool.index_of(dec[0])
-        k2, pj = pool.index_of(mlp[0])
+        a, b = (pool.index_of(dec[0]) if dec else None), (pool.index_of(mlp[0]) if mlp else None)
+        if a is None or b is None:
+            return None                       # a parameter outside the pool (frozen / not optimised): no early bucket
+        (k, pi), (k2, pj) = a, b
         offs = pool.opts[k].flat['offs']
         if k != k2 or pj != pi + len(dec):
             return None                       # not laid out [.. decoder | mlp ..]: no early bucket
@@ -746,6 +765,7 @@ class Council_Trainer(nn.Module):
         if self._graph_mode:
             self._rep_cache.clear()            # the static input buffers hold a new batch: repeat it again (inside the body)
             self._iter_eager, self._phase = False, 1       # a new iteration starts here (train.py:244-250 call order)
+            self._iter_serials = {}                        # kind -> capture serial of the segments replayed so far in it
         ctx, tok = self._side_stream(0, x, groups, prologue=True)
         with ctx:
             # ---- host part: the reference's RNG draws (trainer_council.py:741,744), staged into static device buffers
@@ -1050,6 +1070,9 @@ class Council_Trainer(nn.Module):
                             rng = self._dec_bucket(d, lead)
                             if rng is not None:
                                 def _start(grad, rng=rng):
+                                    # the decoder's weight gradients may still be accumulating on the companion stream
+                                    # (CG_WGRAD_STREAM=1): the in-place all-reduce of their bucket starts behind them
+                                    ops.wgrad_join()
                                     early.append(rng + (self.shard.replica_mean_begin(pool.grad[rng[0]:rng[1]]),))
                                     return grad
                                 content_in.register_hook(_start)

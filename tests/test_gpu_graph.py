@@ -79,7 +79,7 @@ def _run(cga, cfg, graph, iters, size, group_max=None, overlap=None, expect_grap
     steps = [list(o._steps) for o in tr.gen_opt_s]
     ring = {d: list(tr._ring_pos[d]) for d in tr._dirs}
     captured = tr.__dict__.get('_n_captures', 0)      # captures over the run (a new key of a kind evicts the old graph)
-    assert sum(1 for s in tr._segs.values() if s.graph is not None) <= 4
+    assert sum(1 for s in tr._segs.values() if s.graph is not None) <= 8       # at most CG_GRAPH_KEEP = 2 resident captures per kind
     if expect_graph_mode_after is not None:
         assert tr._graph_mode == expect_graph_mode_after
     del tr
@@ -171,9 +171,9 @@ def test_graph_mode_recaptures_when_the_schedule_changes(cga):
         assert torch.equal(e_w[k], g_w[k]), k
 
 
-def test_graph_mode_host_cost(cga):
-    """The point of the exercise: at full width (male2female 256x256, council 4, batch 1) the host enqueues a replayed
-    iteration in a few milliseconds (eager: ~17 ms of Python + launch calls)."""
+def full_width_eager_vs_graph(cga, iters_warm=4, iters_timed=5):
+    """male2female 256x256, council 4, batch 1 at the shipped widths, eager then replayed: returns
+    {graph: (median host enqueue ms, median total ms, generator losses)}.  Shared with tests/test_gpu_perf.py."""
     cfg = yaml.safe_load(open(os.path.join(CONFIGS, "male2female_council_folder.yaml")))
     cfg['council']['council_size'] = 4
     cfg['batch_size'] = 1
@@ -191,19 +191,25 @@ def test_graph_mode_host_cost(cga):
 
             def step():
                 tr.dis_update(x_a, x_b, c); tr.dis_council_update(x_a, x_b, c); tr.gen_update(x_a, x_b, c, 60000)
-            for _ in range(4):
+            for _ in range(iters_warm):
                 step()
             torch.cuda.synchronize()
             host, total = [], []
-            for _ in range(5):
+            for _ in range(iters_timed):
                 t0 = time.perf_counter(); step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
                 host.append(1e3 * (t1 - t0)); total.append(1e3 * (t2 - t0))
             res[graph] = (float(np.median(host)), float(np.median(total)), [float(v) for v in tr.loss_gen_total_s])
             del tr
     finally:
         cga.ops.X3_FORWARD = cga.ops.X3_BACKWARD = cga.ops.X3_DYNAMIC_INPUT = True
+    return res
+
+
+def test_graph_mode_full_width(cga):
+    """At full width (male2female 256x256, council 4, batch 1) nine replayed iterations end on the same generator losses, bit for
+    bit, as nine eager ones.  The wall-clock side of this run (host enqueue cost, total time) is asserted in
+    tests/test_gpu_perf.py under the `perf` marker -- a timing assertion must not be able to stop the parity suite."""
+    res = full_width_eager_vs_graph(cga)
     print("\n[graph mode] host enqueue per iteration: eager %.1f ms (GPU done after %.1f ms), graph %.1f ms (GPU done after %.1f ms)"
           % (res[False][0], res[False][1], res[True][0], res[True][1]))
     assert res[True][2] == res[False][2]
-    assert res[True][0] <= 5.0, res
-    assert res[True][1] <= 1.05 * res[False][1], res

@@ -1360,3 +1360,32 @@ def test_bounded_split_chain_and_fused_activation_backward(cga, n, first, monkey
         for li, (w, b) in enumerate(ws):
             assert rel(nets[m][li].weight._cg_grad, w.grad) < TOL, ("weight gradient", m, li)
             assert rel(nets[m][li].bias._cg_grad, b.grad) < 5 * TOL, ("bias gradient", m, li)
+
+
+def test_value_keyed_device_constants_are_valid_on_every_stream(cga):
+    """ops.take_rows caches its row-index vector on the device BY VALUE, and the cache is read from whatever stream asks next
+    (the two discriminator-side updates run on two side streams).  The entry must be complete when it is published: a second
+    stream that hits the cache while the first stream's queue is still long must read the indices, not the fresh allocation's
+    previous contents (round 4: an out-of-bounds gather -> `Memory access fault` in the driver's run).  Same for the LSGAN
+    target / weight vectors (networks._LossVectors)."""
+    ops = cga.ops
+    x = torch.randn(64, 8, 8, 8, device='cuda').contiguous(memory_format=torch.channels_last)
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    filler = torch.randn(1 << 24, device='cuda')
+    vec = cga.networks._LossVectors()
+    torch.cuda.synchronize()
+    for trial in range(6):
+        idx = [(7 * trial + 3 * i + 1) % 64 for i in range(37 + trial)]          # a tuple no earlier test has used
+        tgt = [float((trial + i) % 2) for i in range(19 + trial)]
+        with torch.cuda.stream(a):
+            for _ in range(40):
+                ops.fill_(filler, float(trial))                                  # a few ms of queued work ahead of the miss
+            ya = ops.take_rows(x, None, idx)
+            ta, _ = vec.get(tgt, tgt, x.device)
+        with torch.cuda.stream(b):
+            yb = ops.take_rows(x, None, idx)                                     # cache hit, no ordering against stream a
+            tb, _ = vec.get(tgt, tgt, x.device)
+            tb = tb.clone()
+        torch.cuda.synchronize()
+        assert torch.equal(ya, x[idx]) and torch.equal(yb, x[idx])
+        assert tb.tolist() == tgt and ta.tolist() == tgt

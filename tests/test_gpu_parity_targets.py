@@ -150,3 +150,29 @@ def test_member_grouping_is_exact_on_fp32_datapath(cga):
         worst = max(worst, e)
         assert e <= 1e-5, ("grouped vs member-by-member gradients", key, e)
     print("\n[member grouping, fp32 datapath] worst l2-rel gradient difference CG_GROUP=4 vs 1: %.1e" % worst)
+
+
+def test_layernorm_discriminators_iteration_vs_oracle(cga):
+    """`dis.norm: ln` (reference networks.py:484-485 -> LayerNorm, networks.py:659-686): no shipped YAML selects it, but it
+    is the one place LayerNorm is reachable on the hot path, and north_star names the operator.  One whole iteration of a
+    narrow council of two (discriminators and council discriminators with a per-sample LayerNorm after every strided
+    convolution but the first) against the oracle: cg_layernorm_fwd / cg_layernorm_bwd under the real losses, their
+    gamma / beta gradients and Adam steps included.  Narrow (dim 16) so that the oracle's three passes take seconds."""
+    cfg = _cfg("male2female_council_folder.yaml", 2)
+    cfg['gen'].update(dim=16, mlp_dim=32, n_res=2)
+    cfg['dis'].update(dim=16, norm='ln')
+    seen = []
+    orig = cga.ops.layer_norm
+
+    def spy(x, gamma, beta, eps=1e-5):
+        seen.append(tuple(x.shape))
+        return orig(x, gamma, beta, eps)
+    cga.ops.layer_norm = spy
+    try:
+        errs = P.iteration_vs_oracle(cga, cfg, 64, 2, seed=9, report="male2female 64^2 council 2 B2, dis.norm = ln")
+    finally:
+        cga.ops.layer_norm = orig
+    assert seen, "no LayerNorm launch: the configuration did not reach cg_layernorm_fwd"
+    assert "loss/disc_total" in errs
+    # the LayerNorm parameters themselves took part in the comparison (gradients of gamma / beta of both discriminator kinds)
+    assert any(k[0] == "grad" and k[1] in ("dis", "disc") for k in errs if not isinstance(k, str))
