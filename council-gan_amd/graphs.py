@@ -66,6 +66,7 @@ class Segment:
         self.out = None
         self.effects = []
         self.generation = -1
+        self.ws = {}              # scratch buffers of the captured launches (hip.capture_workspaces): live as long as the graph
         self.serial = 0           # capture number (trainer-wide) of the current graph
         self.parents = {}         # kind -> serial of the earlier segments of the iteration this graph was captured behind
         self.used = 0             # trainer-wide use clock (least recently used segment of a kind is evicted first)

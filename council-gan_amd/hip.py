@@ -242,15 +242,56 @@ _PTR_DTYPES = frozenset((torch.float32, torch.int32, torch.uint8, torch.float16)
 
 
 _ws_cache = {}
+_ws_scope = None       # the workspace table of the hipGraph capture in progress (capture_workspaces), or None
+
+
+class capture_workspaces:
+    """`with hip.capture_workspaces(table):` around a hipGraph capture -- every workspace() call inside takes its scratch from
+    `table` (a dict the graph's owner keeps for as long as the graph lives) instead of the process-wide per-stream cache.
+
+    Why: a captured kernel bakes the address of its scratch buffer.  The process-wide cache is keyed by the raw stream handle,
+    and torch hands out the same 32 handles round-robin -- so the capture stream of a new trainer can find a buffer that an
+    EARLIER trainer allocated eagerly on that handle.  Baked into the graph, that buffer is then dropped from the cache the
+    next time some launch on the handle needs a larger one, returns to the caching allocator, and the next capture's
+    `torch.cuda.empty_cache()` (torch.cuda.graph.__enter__ calls it) unmaps it: the graph's next replay writes to freed memory --
+    round 4's `Memory access fault ... Write access to a read-only page` in the driver's run (it needed the earlier tests of the
+    same process to seed the cache, which is why the test passed on its own).  Buffers allocated inside the capture come from
+    the graph's private pool; buffers a capture outgrows stay in the table (earlier kernels of the graph still use them)."""
+
+    def __init__(self, table):
+        self.table = table
+
+    def __enter__(self):
+        global _ws_scope
+        self.prev, _ws_scope = _ws_scope, self.table
+        return self.table
+
+    def __exit__(self, *exc):
+        global _ws_scope
+        _ws_scope = self.prev
+        return False
 
 
 def workspace(nbytes, slot=0):
     """Per-device scratch owned by PyTorch's caching allocator; kernels on one stream are ordered,
-    so one buffer per device (and slot) is shared by every op.  Slot 1 carries the instance-norm partials
-    from a convolution epilogue to the norm that follows it."""
+    so one buffer per stream (and slot) is shared by every op.  Slot 1 carries the instance-norm partials
+    from a convolution epilogue to the norm that follows it.  Inside a hipGraph capture the buffers belong to the graph
+    (capture_workspaces)."""
+    if _ws_scope is not None:
+        key = (_stream_handle(), slot)
+        buf = _ws_scope.get(key)
+        if buf is None or buf.numel() < nbytes:
+            n = (max(int(nbytes), 1 << 20) + (1 << 20) - 1) & ~((1 << 20) - 1)
+            if buf is not None:
+                _ws_scope.setdefault('retired', []).append(buf)      # kernels captured so far keep writing to it
+            buf = _ws_scope[key] = torch.empty(n, dtype=torch.uint8, device="cuda")
+        return buf
     dev = (_stream_handle(), slot)   # one scratch per stream (stream handles are unique across devices)
     buf = _ws_cache.get(dev)
     if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise HipError("workspace(): allocation inside a hipGraph capture outside hip.capture_workspaces(...): the buffer "
+                           "would be baked into the graph and later freed by the process-wide cache")
         n = max(int(nbytes), 1 << 20)
         n = (n + (1 << 20) - 1) & ~((1 << 20) - 1)
         buf = torch.empty(n, dtype=torch.uint8, device="cuda")

@@ -537,7 +537,7 @@ class Council_Trainer(nn.Module):
                     torch.cuda.synchronize(self._device)
                     for k in same[:len(same) - keep + 1]:
                         old = self._segs.pop(k)
-                        old.graph, old.out, old.effects = None, None, []
+                        old.graph, old.out, old.effects, old.ws = None, None, [], {}
                 seg = self._segs[key] = Segment()
             if seg.graph is not None and seg.generation != self._hin.generation:
                 seg.graph, seg.warm = None, 0                      # a static input buffer moved: capture again
@@ -546,7 +546,7 @@ class Council_Trainer(nn.Module):
                 # re-captured or evicted since): the tensors it reads from their pools -- content codes, the repeated batch, the
                 # translations -- have moved.  Its warm-up has happened; capture again, behind the current ones.
                 torch.cuda.synchronize(self._device)
-                seg.graph, seg.out, seg.effects = None, None, []
+                seg.graph, seg.out, seg.effects, seg.ws = None, None, [], {}
             self._seg_clock = self.__dict__.get('_seg_clock', 0) + 1
             seg.used = self._seg_clock
             if self._iter_eager or (seg.graph is None and seg.warm < self._graph_warmup):
@@ -577,7 +577,11 @@ class Council_Trainer(nn.Module):
                         # capture_error_mode "thread_local": only the capturing thread is policed.  Under "global" (torch's
                         # default) a potentially-unsafe HIP call from ANY thread invalidates the capture -- and the
                         # collective library's watchdog thread polls hipEventQuery on the image exchange it has just run
-                        with torch.cuda.graph(g, stream=cap, capture_error_mode=os.environ.get('CG_GRAPH_CAPTURE_MODE', 'thread_local')):
+                        # scratch buffers of the captured launches belong to THIS graph (hip.capture_workspaces: a buffer from
+                        # the process-wide per-stream cache would be baked in and later freed under the graph)
+                        seg.ws = {}
+                        with hip.capture_workspaces(seg.ws), \
+                                torch.cuda.graph(g, stream=cap, capture_error_mode=os.environ.get('CG_GRAPH_CAPTURE_MODE', 'thread_local')):
                             seg.out = body()
                         seg.effects = self._recording
                     except Exception as e:      # noqa: BLE001 -- whatever stopped the capture, the eager path below still stands

@@ -356,3 +356,55 @@ def smooth_backward_errors(cga, cfg, size=64, batch=2, seed=21, head_scale=0.02,
             errs[(m, kk)] = e / n
     del tr
     return errs, ferr
+
+
+def gen_grad_ratios(cga, cfg, size, batch, seed=1, datapaths=("fp32", "split"), report=None):
+    """Generator-gradient error of the HIP trainer RELATIVE TO the reference arithmetic's own, on one configuration:
+    err(ours, fp64 oracle) / err(fp32 oracle, fp64 oracle) per generator, for each datapath (`cg_forward_precision`), from ONE
+    evaluation of the two oracles (the expensive part) and one HIP iteration per datapath, all from identical weights, inputs
+    and host-RNG state.  Returns {datapath: {(d, i): (err ours, err fp32 oracle, ratio)}} plus 'e_ref_run' (largest fp32-oracle
+    gap over the members) and 'loss_err' {datapath: largest relative loss error vs the fp32 oracle}.
+    SURVEY.md section 7 / 8c states the contract as err(ours) <= 2 x err(ref32)."""
+    cfg = copy.deepcopy(cfg)
+    cfg['batch_size'] = batch
+    cfg['new_size'] = cfg['crop_image_height'] = cfg['crop_image_width'] = size
+    out, state, rng, x_a, x_b = {}, None, None, None, None
+    runs = {}
+    for dp in datapaths:
+        c = copy.deepcopy(cfg)
+        c['cg_forward_precision'] = dp
+        O.seed_all(seed)
+        tr = cga.Council_Trainer(copy.deepcopy(c), 'cuda:0')
+        if state is None:
+            state = host_state(tr)
+        tr.cuda('cuda:0')
+        x_a, x_b = O.synthetic_batch(batch, size)
+        rng = (random.getstate(), torch.get_rng_state())
+        tr.dis_update(x_a, x_b, c)
+        tr.dis_council_update(x_a, x_b, c)
+        tr.gen_update(x_a, x_b, c, c['iteration'])
+        torch.cuda.synchronize()
+        runs[dp] = ({(d, i): grads_of(tr._nets('gen', d)[i]) for d in tr._dirs for i in range(tr.council_size)},
+                    lossvec(tr.loss_gen_total_s))
+        del tr
+        random.setstate(rng[0]); torch.set_rng_state(rng[1])
+    o32, g32, _, _ = run_oracle(cfg, state, x_a, x_b, rng, torch.float32)
+    _, g64, _, _ = run_oracle(cfg, state, x_a, x_b, rng, torch.float64)
+    gens = [k for k in g64 if k[0] == "gen"]
+    e_ref = {k[1:]: l2rel(g32[k], g64[k]) for k in gens}
+    out['e_ref_run'] = max(e_ref.values())
+    out['loss_err'] = {}
+    for dp, (gs, lv) in runs.items():
+        ref = lossvec(o32.loss_gen_total)
+        out['loss_err'][dp] = float(np.max(np.abs(lv - ref) / np.maximum(np.abs(ref), 1e-7)))
+        out[dp] = {}
+        for k in gens:
+            e = l2rel(gs[k[1:]], g64[k])
+            out[dp][k[1:]] = (e, e_ref[k[1:]], e / out['e_ref_run'])
+    if report is not None:
+        for dp in datapaths:
+            print("[%s] datapath %-5s generator-gradient l2-rel vs fp64: %s | fp32 oracle's own gap: largest %.2e | "
+                  "ratio to it: %s | gen_total loss vs fp32 oracle %.1e"
+                  % (report, dp, {"%s/%d" % k: "%.2e" % v[0] for k, v in out[dp].items()}, out['e_ref_run'],
+                     {"%s/%d" % k: "%.2f" % v[2] for k, v in out[dp].items()}, out['loss_err'][dp]))
+    return out

@@ -206,6 +206,17 @@ def test_two_iterations_vs_reference(cga, name):
                     np.testing.assert_allclose(mine, ref, rtol=LT, atol=1e-7)
 
         # ---- gradients and post-step weights --------------------------------------------------
+        # the fixture's own fp32-vs-fp64 generator-gradient gap (largest over the members: they draw from one lottery), from the
+        # tensors it stores whole -- what the level criterion and the norm band below are derived from
+        import parity_util
+        xa = g["x_a"]
+        pixels = int(xa.shape[0] * xa.shape[2] * xa.shape[3])
+        e_ref_run = 0.0
+        for (kind, d, i) in got:
+            if kind == "gen":
+                rf = g.sub(pre + "gen/grad/%s/%d/" % (d, i))
+                if rf:
+                    e_ref_run = max(e_ref_run, l2rel(rf, {k: v for k, v in g64[(kind, d, i)].items() if k in rf}))
         for (kind, d, i), (gs, ws) in got.items():
             net = kinds[kind][0]
             ref_sum = g[pre + "%s/gradsum/%s/%d" % (kind, d, i)]
@@ -218,9 +229,14 @@ def test_two_iterations_vs_reference(cga, name):
                 assert not bad.any(), (kind, d, i, mine[bad], ref_sum[bad])
             elif g.from_seed and it == 0:
                 # full-width generator: every tensor's gradient norm against the reference's (the 17 M-element tensors
-                # are not stored whole); the reference's own fp32 noise is 2-4e-3 and chaotic in the forward round-off
-                # (parity_util.GEN_GRAD_FACTOR): a norm can be off by the common relative error, nothing more
-                bad = np.abs(mine[:, 1] - ref_sum[:, 1]) > 6e-2 * ref_sum[:, 1] + 1e-4 * scale
+                # are not stored whole).  | ||ours|| - ||ref|| | <= ||ours - ref|| <= ||ours - fp64|| + ||ref - fp64||: the
+                # band is the level the whole-tensor criterion allows THIS run (parity_util.gen_grad_limit on the fixture's
+                # own fp32-vs-fp64 gap) plus that gap -- not a constant (it was 6e-2 until round 4)
+                band = parity_util.gen_grad_limit(pixels, e_ref_run) + e_ref_run
+                dev_n = np.abs(mine[:, 1] - ref_sum[:, 1]) / (ref_sum[:, 1] + 1e-4 * scale)
+                print("[norm band] %s %s %d: largest per-tensor norm deviation %.2e, band %.2e (fixture gap %.2e)"
+                      % (kind, d, i, float(dev_n.max()), band, e_ref_run))
+                bad = np.abs(mine[:, 1] - ref_sum[:, 1]) > band * ref_sum[:, 1] + 1e-4 * scale
                 assert not bad.any(), (kind, d, i, mine[bad], ref_sum[bad])
             ref_full = g.sub(pre + "%s/grad/%s/%d/" % (kind, d, i))
             if ref_full:
@@ -232,10 +248,9 @@ def test_two_iterations_vs_reference(cga, name):
                 if kind == "gen":
                     # north star: within 1e-3 rel-fp32; where the reference's own fp32-vs-fp64 gap is larger than that
                     # (steep mask head) the measured chaos band of the reference arithmetic
-                    import parity_util       # level + per-tensor uniformity, see parity_util.check_gen_grad
-                    xa = g["x_a"]
-                    parity_util.check_gen_grad({k: gs[k] for k in r64}, ref_full, r64, (it, d, i),
-                                               pixels=int(xa.shape[0] * xa.shape[2] * xa.shape[3]))
+                    # level + per-tensor uniformity, see parity_util.check_gen_grad
+                    parity_util.check_gen_grad({k: gs[k] for k in r64}, ref_full, r64, (it, d, i), pixels=pixels,
+                                               e_ref_run=e_ref_run)
                 else:
                     assert e_ours <= ACT_TOL, ("discriminator gradient", kind, it, d, i, e_ours, e_ref)
             # post-step weights: one Adam step moves every weight by <= lr; compare the bulk

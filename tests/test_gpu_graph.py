@@ -213,3 +213,41 @@ def test_graph_mode_full_width(cga):
     print("\n[graph mode] host enqueue per iteration: eager %.1f ms (GPU done after %.1f ms), graph %.1f ms (GPU done after %.1f ms)"
           % (res[False][0], res[False][1], res[True][0], res[True][1]))
     assert res[True][2] == res[False][2]
+
+
+def test_captured_launches_own_their_workspaces(cga):
+    """Round 4's driver abort (`Memory access fault ... Write access to a read-only page` after four full-width iterations): the
+    scratch cache is keyed by the raw stream handle, torch recycles 32 handles, so a capture could bake in a buffer some EARLIER
+    trainer had allocated eagerly on the same handle; the cache later replaced it, and the next capture's torch.cuda.empty_cache()
+    unmapped it under the graph.  Inside hip.capture_workspaces(table) a capture takes every buffer from its own table (private
+    pool memory that lives as long as the graph's owner keeps the table), never from the process-wide cache."""
+    hip = cga.hip
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        eager = hip.workspace(1 << 20, slot=7)                        # what an earlier trainer left behind on this handle
+        assert hip.workspace(1 << 19, slot=7) is eager
+    torch.cuda.synchronize()
+    table, g = {}, torch.cuda.CUDAGraph()
+    x = torch.zeros(1 << 18, device='cuda')
+    with hip.capture_workspaces(table), torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):
+        a = hip.workspace(1 << 19, slot=7)
+        cga.ops.fill_(a.view(torch.float32)[:1 << 17], 3.0)
+        b = hip.workspace(3 << 20, slot=7)                            # outgrown inside the same capture: `a` must stay alive
+        cga.ops.fill_(b.view(torch.float32)[:1 << 18], 5.0)
+        x.copy_(b.view(torch.float32)[:1 << 18])
+    assert a.data_ptr() != eager.data_ptr() and b.data_ptr() != eager.data_ptr()
+    assert any(t is a for t in table.get('retired', []))
+    with torch.cuda.stream(st):
+        assert hip.workspace(1 << 19, slot=7) is eager                # outside the capture: the process-wide cache, untouched
+        hip.workspace(8 << 20, slot=7)                                # ... which may now grow and drop its old buffer
+    del eager
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                                          # what the NEXT capture's __enter__ does
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(x.min()) == 5.0 and float(a.view(torch.float32)[0]) == 3.0
+    # and without a table an allocation inside a capture is refused instead of baked in
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(cga.hip.HipError, match="capture_workspaces"):
+        with torch.cuda.graph(g2, stream=st, capture_error_mode='thread_local'):
+            hip.workspace(64 << 20, slot=7)
