@@ -617,7 +617,7 @@ def main():
             if kernel_peak(dname) == F16X3_PEAK_TFLOPS:
                 # what the matrix pipe sustains on this very instruction mix with NO memory traffic at all (3 dependent-free
                 # v_mfma_f32_32x32x16_f16 per product, 8 accumulators per wave, one block per CU, power-limited clock):
-                # committed measurement, tools/attic/probe/mfma_mix.hip -> profiles/r03_mfma_mix.txt
+                # committed measurement, tools/probes/mfma_mix.hip -> profiles/r03_mfma_mix.txt
                 roof["pipe_ceiling"] = {"value": MFMA_MIX_CEILING_TFLOPS, "unit": "TFLOP/s (a.b products)",
                                         "frac": round(ach / MFMA_MIX_CEILING_TFLOPS, 4), "source": "profiles/r03_mfma_mix.txt"}
         else:

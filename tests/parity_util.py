@@ -29,7 +29,7 @@ ACT_TOL = 1e-3
 #     measured 1.5e-4 ... 2e-3 l2-rel), a few times more on sequential fp32 MFMA accumulation, and
 #     ~20 x more on the 22-bit split-precision operands (round-off 2e-6 on cancelling sums) -- sqrt(20) ~ 4.5 x the error;
 #   * with smooth activations (tanh instead of ReLU) the SAME kernels agree with fp64 to 1e-5 on every tensor
-#     (tools/attic/diag_smooth.py, profiles/r03_smooth_backward.txt; test_generator_backward_chain_smooth_loss[tanh]) -- the
+#     (tools/probes/diag_smooth.py, profiles/r03_smooth_backward.txt; test_generator_backward_chain_smooth_loss[tanh]) -- the
 #     backward arithmetic is not where the difference comes from; swapping the split-precision backward kernels for the
 #     exact-fp32 ones leaves the error unchanged to three digits: it is decided in the forward pass;
 #   * which elements flip is a lottery: re-running the reference arithmetic itself with every Conv2dBlock output perturbed

@@ -61,7 +61,7 @@ def _run(cga, cfg, graph, iters, size, group_max=None, overlap=None, expect_grap
         tr.gen_update(x_a, x_b, c, c['iteration'])
         torch.cuda.synchronize()
         row = {n: [float(v) for v in getattr(tr, n, [])] for n in names}
-        if os.environ.get('CG_DIAG_POOLS'):      # per-pool checksums of weights / gradients / moments (tools/attic/diag_graph.py)
+        if os.environ.get('CG_DIAG_POOLS'):      # per-pool checksums of weights / gradients / moments (tools/probes/diag_graph.py)
             for kind, pool in tr._pools.items():
                 for nm in ('data', 'grad', 'm', 'v'):
                     row['%s.%s' % (kind, nm)] = [float(getattr(pool, nm).double().abs().sum())]
