@@ -1560,6 +1560,7 @@ static void tuning_from_env() {
     t.no_amax_atomic = getenv("CG_NO_AMAX_ATOMIC") != nullptr;
     t.wgrad_x3_multitap = env_int("CG_WGRAD_X3_MULTITAP", 1) != 0;
     t.x3_cls_minor = env_int("CG_X3_CLS_MINOR", 1) != 0;
+    t.x3_generic_epilogue = env_int("CG_X3_GENERIC_EPILOGUE", 0) != 0;
     g_tune = t;
 }
 static cg_tuning& tune() {

@@ -319,7 +319,10 @@ typedef struct cg_tuning {
     int32_t wgrad_x3_multitap; /* CG_WGRAD_X3_MULTITAP (1): 128-wide K-tiles spanning several taps for 32 / 64 input channels */
     int32_t x3_cls_minor;    /* CG_X3_CLS_MINOR (1): multi-class launches (strided data gradients, upsample-convolutions) order their blocks
                               * class-minor, so that the output-parity classes of one row tile share an XCD's L2 */
-    int32_t reserved[3];
+    int32_t x3_generic_epilogue; /* CG_X3_GENERIC_EPILOGUE (0): A/B switch -- 1 = the split-precision forward / data-gradient kernels always take
+                              * the generic copy of their epilogue value loop (round 4's code path) instead of the copies compiled for
+                              * {no activation, LeakyReLU} x {with, without statistics}; results are bit-identical either way */
+    int32_t reserved[2];
 } cg_tuning;
 int cg_tuning_get(cg_tuning* out);
 int cg_tuning_set(const cg_tuning* in);

@@ -50,7 +50,7 @@ def run_x3(lib, g, xs, ws, b, y, cfg):
 
 
 def operands(lib, N, H, W, Cin, Cout, K, stride, pad, up):
-    g = ops.fwd_geom(N, H, W, Cin, 0, up, K, K, stride, pad, Cout, 1)
+    g = ops.fwd_geom(N, H, W, Cin, 0, up, K, K, stride, pad, Cout, int(os.environ.get('AB_ACT', '1')))      # AB_ACT=0: no fused activation
     x = torch.randn(N, Cin, H, W, device="cuda").contiguous(memory_format=CL)
     w = (torch.randn(Cout, Cin, K, K, device="cuda") * 0.05).contiguous(memory_format=CL)
     return g, split(lib, x), split(lib, w, hip.X3_WSCALE), torch.randn(Cout, device="cuda")

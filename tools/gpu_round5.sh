@@ -10,7 +10,7 @@ for stage in "$@"; do
     seq)       run seq timeout 300 python -m pytest tests/test_gpu_golden.py tests/test_gpu_graph.py -x -q -s -p no:cacheprovider ;;
     ops)       run ops timeout 300 python -m pytest tests/test_gpu_ops.py -x -q -p no:cacheprovider ;;
     graph)     run graph timeout 300 python -m pytest tests/test_gpu_graph.py -x -q -s -p no:cacheprovider ;;
-    ab)        EXTRA_SHAPES="res16,16,64,64,256,256,3,1,1,0;res32,32,64,64,256,256,3,1,1,0;dc128_256,16,128,128,128,256,4,2,1,0" run ab timeout 300 python tools/ab_x3.py ${AB_CFGS:-16,48,46,47} 0 ;;
+    ab)        AB_ACT=${AB_ACT:-1} EXTRA_SHAPES="res16,16,64,64,256,256,3,1,1,0;res32,32,64,64,256,256,3,1,1,0;dc128_256,16,128,128,128,256,4,2,1,0" run ab timeout 300 python tools/ab_x3.py ${AB_CFGS:-16,48,46,47} 0 ;;
     bench)     run bench timeout 600 python bench.py --no-cpu-baseline --no-other-configs --no-exact-fp32 ;;
     bench_full) run bench_full timeout 900 python bench.py ;;
     ratio)     run ratio env CG_LONG_ORACLE=1 timeout 1200 python -m pytest tests/test_gpu_parity_full.py -x -q -s -k generator_gradient_ratio -p no:cacheprovider ;;
