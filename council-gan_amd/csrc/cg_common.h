@@ -23,6 +23,11 @@ int cg_set_error(int code, const char* fmt, ...);
 
 static inline hipStream_t cg_s(cg_stream_t s) { return (hipStream_t)s; }
 
+// An unconditional use of a loaded per-lane value right behind its load: retires hipcc's "pending load" state on every path, so
+// that the exec-masked per-value blocks of an epilogue do not each start with s_waitcnt vmcnt(0) -- which on gfx950 also waits for
+// the previous block's STORE (stores count in vmcnt).  See conv_x3.inc, "Epilogue hygiene".
+__device__ __forceinline__ void cg_touch(float v) { asm volatile("" ::"v"(v)); }
+
 __device__ __forceinline__ float cg_apply_act(float v, int act) {
     switch (act) {
         case CG_ACT_RELU: return v > 0.f ? v : 0.f;

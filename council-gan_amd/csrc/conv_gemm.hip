@@ -321,6 +321,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_kernel(
         const int col = n0 + wn0 + j * 32 + l31;
         if (col >= g.Cout) continue;
         const float bj = bias ? bias[col] : 0.f;
+        cg_touch(bj);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(512) void conv_fwd_thin_kernel(
         breg[kp] = j < RL ? v : 0.f;
     }
     const float bj = bias ? bias[wn * 32 + l31] : 0.f;
+    cg_touch(bj);
 
     // LDS offsets of this lane's two A rows: row r of the tile is pixel (r / 16, r % 16)
     int rb[2];
@@ -921,6 +923,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kern
         const int col = n0 + wn0 + j * 32 + l31;
         if (col >= g.Cout) continue;
         const float bj = bias ? bias[col] : 0.f;
+        cg_touch(bj);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
