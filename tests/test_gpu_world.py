@@ -131,8 +131,11 @@ def test_sharded_trainer_matches_single_process(world, council):
         assert abs(vs[0] - ref[2][m]) <= 1e-3 * max(abs(ref[2][m]), 1.0)
 
 
-def test_replicated_members_vs_oracle():
-    """SURVEY.md 8f.4 against the ORACLE (VERDICT r3 item 3 iii), not against this repo's own single-process run: council 2
+@pytest.mark.parametrize("wgrad_stream", [False, True])
+def test_replicated_members_vs_oracle(wgrad_stream, monkeypatch):
+    """(wgrad_stream = True: CG_WGRAD_STREAM=1 in the ranks -- the decoder's weight gradients accumulate on the companion stream, and
+    the early all-reduce of their bucket, started from the content-code hook, must begin behind them: ADVICE r4.)
+    SURVEY.md 8f.4 against the ORACLE (VERDICT r3 item 3 iii), not against this repo's own single-process run: council 2
     on four ranks -- every member on two replicas, half a batch each, gradients averaged inside the member, the focus-loss
     sums and the loss-matching values averaged before use -- must give the reference's FULL-batch iteration
     (/root/reference/trainer_council.py:735-780, focus terms :230-250): every loss and the discriminator / council-
@@ -157,6 +160,8 @@ def test_replicated_members_vs_oracle():
     otr.gen_update(x_a, x_b, cfg, 60000)
     want = [P.lossvec(v) for v in (otr.loss_dis_total, otr.loss_disc_total, otr.loss_gen_total, otr.loss_gen_adv['a2b'],
                                    otr.council_loss['a2b'])]
+    if wgrad_stream:
+        monkeypatch.setenv("CG_WGRAD_STREAM", "1")       # spawned ranks read it when they import council_gan_amd.ops
     res = _run(4, council, iters=1, want_grads=True)
     assert res[0][3] == 2
     for r in res:
