@@ -622,3 +622,25 @@ def test_ctypes_signatures_match_the_header():
         if got != want or cls(res) != want_ret:
             bad.append((name, want_ret + ":" + "".join(want), cls(res) + ":" + "".join(got)))
     assert not bad, bad
+
+
+def test_gpu_suite_order_and_perf_marker():
+    """with `-x`, one fault must not hide the cheap, wide parity tests -- the GPU suite collects operators first
+    and the heavy full-width graph runs last (tests/conftest.py: _ORDER), and wall-clock assertions are not part of `-m gpu` at all."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", "tests", "-q", "-m", "gpu", "--collect-only", "-p", "no:cacheprovider"],
+                         cwd=root, capture_output=True, text=True, timeout=300).stdout
+    files = []
+    for line in out.splitlines():
+        if "::" in line:
+            f = line.split("::")[0]
+            if not files or files[-1] != f:
+                files.append(f)
+    assert files[0].endswith("test_gpu_ops.py") and files[-1].endswith("test_gpu_graph.py"), files
+    assert len(files) == len(set(files)), files                      # every file's tests stay together
+    assert not any(f.endswith("test_gpu_perf.py") for f in files)    # marker `perf`, not `gpu`
+    perf = subprocess.run([sys.executable, "-m", "pytest", "tests", "-q", "-m", "perf", "--collect-only", "-p", "no:cacheprovider"],
+                          cwd=root, capture_output=True, text=True, timeout=300).stdout
+    assert "test_gpu_perf.py::test_graph_mode_host_cost" in perf
