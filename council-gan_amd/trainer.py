@@ -104,6 +104,12 @@ class Council_Trainer(nn.Module):
         self.do_b2a_conf = hp['do_b2a']
         self.w_match_b2a_conf = 1
         self.w_match_a2b_conf = 1
+        # trainer_council.py:65-68: logged by utils.write_loss like every '*_conf' member; they only move under
+        # focus_loss.do_w_loss_matching_focus, which _check_supported() refuses (False in every shipped config)
+        self.w_match_focus_a2b_conf = 1
+        self.w_match_focus_b2a_conf = 1
+        self.w_match_focus_zero_one_a2b_conf = 1
+        self.w_match_focus_zero_one_b2a_conf = 1
         self.do_council_loss = None
         self._dirs = [d for d in ('a2b', 'b2a') if hp['do_' + d]]
 

@@ -15,7 +15,8 @@ def case_names(kind="train"):
     """Fixture names.  "train": the two-iteration training cases (including the full-width one, whose initial weights
     are re-derived from the seed); "ckpt": the reference-checkpoint cases; "all": both."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    names = [n for n in names if not n.startswith("input_")]      # input_pil.npz: the loader-tail fixture, not a trainer case
+    # input_pil.npz: the loader-tail fixture; pin_*.npz: operator / statistic pins (LayerNorm, bench-shape gradients) -- not trainer cases
+    names = [n for n in names if not n.startswith(("input_", "pin_"))]
     if kind == "all":
         return names
     return [n for n in names if (n in CKPT_CASES) == (kind == "ckpt")]

@@ -20,6 +20,43 @@ def test_fixtures_present():
     assert len(CASES) >= 6
 
 
+def test_layer_norm_pinned_to_reference():
+    """oracle.layer_norm and the `dis.norm: ln` discriminators against tests/golden/pin_layernorm.npz -- outputs and
+    gradients of the reference's own LayerNorm / MsImageDis / MsImageDisCouncil (networks.py:659-686, 24-47, 119-146),
+    recorded by oracle/make_ln_golden.py.  Both branches of LayerNorm.forward (batch 1 / batch > 1)."""
+    import json
+    import os
+    from golden_util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "pin_layernorm.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    for tag in ("b1", "b3"):
+        x = t("ln/%s/x" % tag).requires_grad_(True)
+        gamma = t("ln/%s/gamma" % tag).requires_grad_(True)
+        beta = t("ln/%s/beta" % tag).requires_grad_(True)
+        y = O.layer_norm(x, gamma, beta)
+        (y * t("ln/%s/w" % tag)).sum().backward()
+        for name, ours, ref in (("y", y, "y"), ("dx", x.grad, "dx"), ("dgamma", gamma.grad, "dgamma"), ("dbeta", beta.grad, "dbeta")):
+            assert rel_err(ours.detach().numpy(), z["ln/%s/%s" % (tag, ref)]) <= TOL, (tag, name)
+    hp = json.loads(bytes(z["dis_hp_json"]).decode())
+    assert hp['norm'] == 'ln'
+    for key, cls in (("dis", O.OracleDis), ("dis_council", O.OracleDisCouncil)):
+        sd = {k[len(key) + 4:]: t(k).requires_grad_(True) for k in z.files if k.startswith(key + "/sd/")}
+        net = cls(sd, hp)
+        outs = net.forward(t(key + "/x")) if key == "dis" else net.forward(t(key + "/x"), t(key + "/x_input"))
+        loss = sum(torch.mean((o - 1) ** 2) for o in outs)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(z[key + "/loss"])) <= TOL * abs(float(z[key + "/loss"]))
+        for i, o in enumerate(outs):
+            assert rel_err(o.detach().numpy(), z[key + "/out/%d" % i]) <= TOL, (key, i)
+        n_ln = 0
+        for k in z.files:
+            if k.startswith(key + "/grad/"):
+                name = k[len(key) + 6:]
+                n_ln += name.endswith("norm.gamma")
+                assert rel_err(sd[name].grad.numpy(), z[k]) <= 10 * TOL, (key, name)
+        assert n_ln >= 3      # the fixture really contains LayerNorm layers
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_probe_forward(name):
     g = Golden(name)

@@ -3,6 +3,7 @@ against the first configuration), or a plain launch loop for a rocprofv3 --pmc p
 
     python tools/ab_x3.py 16,38,40 [shape indices, default 0,1,2,3,4,13,14]     A/B table; EXTRA_SHAPES="name,N,H,W,Cin,Cout,K,stride,pad,up;..."
     python tools/ab_x3.py --launch 16 [batch=16] [reps=8]                        res-block shape, `reps` launches (tools/prof_bench.sh PMC=16)
+    PMC_SHAPE="name,N,H,W,Cin,Cout,K,stride,pad,up" python tools/ab_x3.py --launch <cfg>   ... of any other shape (batch argument ignored)
 """
 import os
 import sys
@@ -61,13 +62,17 @@ def launch_loop(argv):
     N = int(argv[1]) if len(argv) > 1 else 16
     reps = int(argv[2]) if len(argv) > 2 else 8
     lib = hip.load()
-    g, xs, ws, b = operands(lib, N, 64, 64, 256, 256, 3, 1, 1, 0)
-    y = torch.empty((N, 256, 64, 64), device="cuda").contiguous(memory_format=CL)
+    shape = (N, 64, 64, 256, 256, 3, 1, 1, 0)
+    if os.environ.get("PMC_SHAPE"):
+        shape = tuple(int(v) for v in os.environ["PMC_SHAPE"].split(",")[1:])
+    g, xs, ws, b = operands(lib, *shape)
+    N, H, W, Cin, Cout, K = shape[:6]
+    y = torch.empty((N, Cout, g.Ho, g.Wo), device="cuda").contiguous(memory_format=CL)
     for _ in range(reps):
         run_x3(lib, g, xs, ws, b, y, cfg)
     torch.cuda.synchronize()
-    print("cfg", cfg, "batch", N, "done; algorithmic bytes per launch: in %.1f MB (hi+lo fp16) + weights %.1f MB + out %.1f MB"
-          % (N * 256 * 4096 * 4 / 1e6, 256 * 256 * 9 * 4 / 1e6, y.numel() * 4 / 1e6))
+    print("cfg", cfg, "shape", shape, "done; %.1f GFLOP; algorithmic bytes per launch: in %.1f MB (hi+lo fp16) + weights %.1f MB + out %.1f MB"
+          % (2.0 * y.numel() * Cin * K * K / 1e9, N * Cin * H * W * 4 / 1e6, Cout * Cin * K * K * 4 / 1e6, y.numel() * 4 / 1e6))
 
 
 def main():

@@ -4,6 +4,8 @@
 #   PMC=16 bash tools/prof_bench.sh <tag>                three --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace
 #                                                        domains besides the kernel trace) of tile configuration 16 on the member-batched
 #                                                        res-block launch: memory-side traffic and matrix-pipe counters of the wide tile
+#   PMC=2 PMC_SHAPE="name,N,H,W,Cin,Cout,K,stride,pad,up" PMC_KERNEL=conv_fwd_x3_kernel ...   the same for another forward shape / kernel
+#   PMC_TOOL="tools/ab_wgrad.py --launch 1" PMC_KERNEL=conv_wgrad PMC=1 ...                   ... for any other launch loop
 TAG=${1:-prof}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -12,7 +14,7 @@ mkdir -p $O
 if [ -n "${PMC:-}" ]; then
   for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
     tag=$(echo $pass | cut -d' ' -f1)
-    timeout -k 5 40 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/$tag -- python $R/tools/ab_x3.py --launch $PMC 16 8 > $O/$tag.log 2>&1 < /dev/null
+    timeout -k 5 60 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/$tag -- python $R/${PMC_TOOL:-tools/ab_x3.py --launch $PMC 16 8} > $O/$tag.log 2>&1 < /dev/null
   done
   python - > $O/summary.txt 2>&1 <<PY
 import csv, glob, collections
@@ -21,10 +23,10 @@ for d in sorted(glob.glob('$O/*/')):
     if not f: continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        if 'conv_fwd_x3w' in r['Kernel_Name']:
+        if '${PMC_KERNEL:-conv_fwd_x3w}' in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
     kt = glob.glob(d+'*/*_kernel_trace.csv')[0]
-    durs=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in csv.DictReader(open(kt)) if 'conv_fwd_x3w' in r['Kernel_Name']]
+    durs=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in csv.DictReader(open(kt)) if '${PMC_KERNEL:-conv_fwd_x3w}' in r['Kernel_Name']]
     print(d.split('/')[-2], 'launches', len(durs), 'avg_us %.1f' % (sum(durs[2:])/max(1,len(durs)-2)), {k: '%.5g' % (sum(v[2:])/max(1,len(v)-2)) for k,v in acc.items()})
 PY
   cat $O/summary.txt
