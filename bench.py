@@ -190,39 +190,51 @@ def build_config(args, world):
 
 
 def cpu_baseline(cfg, tr_state_fn, size, batch_full, timed=2):
-    """Oracle ("port" of the reference) on the host cores, bounded sample: the same council / resolution at batch_size 1,
-    one warm-up iteration + `timed` timed ones, the FASTER of which is reported together with both samples.
-    The iteration's cost is linear in the batch (every operator is per sample; measured 27.9 s at batch 1), so images/sec at
-    batch 1 is the per-image rate the batch-4 GPU line is to be read against; timing batch 4 itself would be ~2 minutes per
-    iteration of a run that must finish within minutes."""
+    """Oracle ("port" of the reference: /root/reference is not on the GPU box) on the host cores, on the configuration the GPU
+    line sits beside: the same council / resolution AT THE SAME BATCH, threads = min(cores, 32) -- the oracle's operators are
+    oneDNN / ATen CPU kernels that stop scaling (and, oversubscribed, slow down) beyond a few tens of threads: round 5's 128-thread
+    batch-1 sample was slower per image than the survey's 8-vCPU reference run.  One batch-1 warm-up
+    iteration (primitive caches, allocator), then `timed` timed iterations at the full batch; the FASTER is reported with both.
+    Calibration of "port" against the real reference, same container, same threads: BASELINE.md section 4 / DESIGN.md section 5."""
     from oracle import council_oracle as O
     cfg = copy.deepcopy(cfg)
-    cfg['batch_size'] = 1
-    otr = O.OracleTrainer(cfg, tr_state_fn())
-    x_a, x_b = O.synthetic_batch(1, size)
-    O.seed_all(1)
-
-    def it():
-        otr.dis_update(x_a, x_b, cfg)
-        otr.dis_council_update(x_a, x_b, cfg)
-        otr.gen_update(x_a, x_b, cfg, cfg['iteration'])
-    t0 = time.time()
-    it()
-    warm = time.time() - t0
-    samples = []
-    for _ in range(timed):
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 32))
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        state = tr_state_fn()
+        cfg1 = copy.deepcopy(cfg)
+        cfg1['batch_size'] = 1
+        O.seed_all(1)
+        warm_tr = O.OracleTrainer(cfg1, state)
+        xa1, xb1 = O.synthetic_batch(1, size)
         t0 = time.time()
-        it()
-        samples.append(time.time() - t0)
+        warm_tr.dis_update(xa1, xb1, cfg1)
+        warm_tr.dis_council_update(xa1, xb1, cfg1)
+        warm_tr.gen_update(xa1, xb1, cfg1, cfg1['iteration'])
+        warm = time.time() - t0
+        del warm_tr
+        cfg['batch_size'] = batch_full
+        otr = O.OracleTrainer(cfg, state)
+        x_a, x_b = O.synthetic_batch(batch_full, size)
+        samples = []
+        for _ in range(timed):
+            t0 = time.time()
+            otr.dis_update(x_a, x_b, cfg)
+            otr.dis_council_update(x_a, x_b, cfg)
+            otr.gen_update(x_a, x_b, cfg, cfg['iteration'])
+            samples.append(time.time() - t0)
+    finally:
+        torch.set_num_threads(prev_threads)
     dt = min(samples)
-    return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "seconds_per_iteration": [round(v, 2) for v in samples],
-            "sample": "oracle/council_oracle.py at batch_size 1 (the GPU line runs batch_size %d; the iteration is per-sample work, "
-                      "so images/sec at batch 1 is the per-image rate to compare with): the same %dx%d council=%d iteration (dis + "
-                      "dis_council + gen updates of all members), 1 warm-up (%.1f s) + %d timed iterations (%s s), fastest reported, "
-                      "%d torch threads"
-                      % (batch_full, size, size, cfg['council']['council_size'], warm, timed,
-                         ", ".join("%.1f" % v for v in samples), torch.get_num_threads())}
+    return {"value": round(batch_full / dt, 5), "unit": "images/sec", "cores": threads, "host_cores": cores, "kind": "port",
+            "batch": batch_full, "seconds_per_iteration": [round(v, 2) for v in samples],
+            "sample": "oracle/council_oracle.py on the GPU line's own configuration: %dx%d council=%d batch=%d, one whole iteration "
+                      "(dis + dis_council + gen updates of all members) per sample; 1 batch-1 warm-up iteration (%.1f s) + %d timed "
+                      "iterations (%s s), fastest reported; %d torch threads = min(%d host cores, 32)"
+                      % (size, size, cfg['council']['council_size'], batch_full, warm, timed,
+                         ", ".join("%.1f" % v for v in samples), threads, cores)}
 
 
 def time_steps(step, fence, warmup, steps, first=0, own=None):
@@ -458,16 +470,24 @@ def main():
         trainer.shard.member_comm = trainer.shard.slice_comm = None
         native_fallback[0] = True
         trainer.cuda(device)
-    x_a, x_b = cga.synthetic_batch(args.batch, args.size)
-    x_a, x_b = x_a.to(device), x_b.to(device)      # inputs resident in HBM before the timed region
+    # inputs resident in HBM before the timed region: a DIFFERENT batch (its own tensor objects, its own pixels) for every step of
+    # a window of up to 32 steps, as a loader would hand them over -- the trainer's per-batch caches (layout conversion, member
+    # replication: trainer.py `_img` / `_rep`) miss once per step exactly as they do in training
+    n_in = max(1, min(args.warmup + args.steps + 1, 32))
+    batches = []
+    for i in range(n_in):
+        xa_i, xb_i = cga.synthetic_batch(args.batch, args.size, seed=7 + i)
+        batches.append((xa_i.to(device), xb_i.to(device)))
+    x_a, x_b = batches[0]
     graph_requested = bool(trainer._graph_mode)
 
     def step(it):
         cfg['iteration'] = 60000 + it
-        trainer.dis_update(x_a, x_b, cfg)
+        xa_s, xb_s = batches[it % n_in]
+        trainer.dis_update(xa_s, xb_s, cfg)
         if council > 1:      # council 1: train.py's call only prints "no council discriminetor is needed" and returns
-            trainer.dis_council_update(x_a, x_b, cfg)
-        trainer.gen_update(x_a, x_b, cfg, cfg['iteration'])
+            trainer.dis_council_update(xa_s, xb_s, cfg)
+        trainer.gen_update(xa_s, xb_s, cfg, cfg['iteration'])
 
     def fence():
         if world > 1:
@@ -579,7 +599,14 @@ def main():
         prof = None
         if not args.no_kernel_profile:
             # a failure of this extra leg must not cost the headline number measured above
+            # shader clock during THIS leg too: a serialised iteration clocks differently from the overlapped timed steps
+            # (per-kernel figures on two boxes differed by 8 % in round 5 with no record of the clock under the events)
+            psamp = GpuSampler(local_rank)
+            psamp.start()
             prof, perr = kernel_profile(cga, trainer, lambda: step(args.warmup + args.steps))
+            psamp.stop_ev.set()
+            psamp.join(timeout=6)
+            roof["kernel_profile_sensors"] = psamp.summary()
             if perr:
                 roof["profile_error"] = perr
         if prof:
@@ -646,6 +673,24 @@ def main():
                                      "steps": n32, "warmup": 2, "dtype": "f32 (v_mfma_f32_32x32x2_f32 everywhere)",
                                      "step_achieved": round(wmin / (ms32 / 1000.0), 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                      "step_frac": round(wmin / (ms32 / 1000.0) / FP32_MFMA_PEAK_TFLOPS, 4)}
+                if not args.no_kernel_profile:
+                    # the same per-kernel evidence as the headline leg: HIP events around every MFMA conv launch of one serialised iteration
+                    prof32, err32 = kernel_profile(cga, tr32, lambda: step32(n32 + 2))
+                    if prof32:
+                        n32k, c32, us32, tf32, pk32 = dominant_kernel(prof32)
+                        t_ms = sum(m for _, m, _ in prof32.values())
+                        t_fl = sum(f for _, _, f in prof32.values())
+                        out["exact_fp32"].update({
+                            "kernel": n32k, "kernel_launches_per_step": c32, "kernel_avg_us": round(us32, 2),
+                            "kernel_tflops": round(tf32, 2), "kernel_peak": round(pk32, 1), "kernel_frac": round(tf32 / pk32, 4),
+                            "conv_ms_per_step": round(t_ms, 2), "all_conv_kernels_tflops": round(t_fl / (t_ms * 1e-3) / 1e12, 2),
+                            "all_conv_frac": round(t_fl / (t_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                            "kernels": {k: {"launches": c, "avg_us": round(1000.0 * ms / c, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                                            "share_of_conv_time": round(ms / t_ms, 4)} for k, (c, ms, fl) in prof32.items()}})
+                        if args.shape_report:
+                            open(args.shape_report + ".exact_fp32", "w").write(cga.hip.prof_report())
+                    elif err32:
+                        out["exact_fp32"]["profile_error"] = err32
                 del tr32
             except Exception as e:      # noqa: BLE001
                 out["exact_fp32"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}

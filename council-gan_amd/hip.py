@@ -3,6 +3,7 @@
 There is NO fallback: if the shared library is missing, or a kernel is called without a GPU,
 this raises.  The product path never routes through PyTorch compute ops or the oracle."""
 import ctypes
+import threading
 import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int8, c_int32, c_int64, c_size_t, c_void_p
 
@@ -242,7 +243,7 @@ _PTR_DTYPES = frozenset((torch.float32, torch.int32, torch.uint8, torch.float16)
 
 
 _ws_cache = {}
-_ws_scope = None       # the workspace table of the hipGraph capture in progress (capture_workspaces), or None
+_ws_tls = threading.local()      # .scope: the workspace table of the hipGraph capture in progress ON THIS THREAD (capture_workspaces), or absent
 
 
 class capture_workspaces:
@@ -262,13 +263,11 @@ class capture_workspaces:
         self.table = table
 
     def __enter__(self):
-        global _ws_scope
-        self.prev, _ws_scope = _ws_scope, self.table
+        self.prev, _ws_tls.scope = getattr(_ws_tls, 'scope', None), self.table
         return self.table
 
     def __exit__(self, *exc):
-        global _ws_scope
-        _ws_scope = self.prev
+        _ws_tls.scope = self.prev
         return False
 
 
@@ -277,6 +276,7 @@ def workspace(nbytes, slot=0):
     so one buffer per stream (and slot) is shared by every op.  Slot 1 carries the instance-norm partials
     from a convolution epilogue to the norm that follows it.  Inside a hipGraph capture the buffers belong to the graph
     (capture_workspaces)."""
+    _ws_scope = getattr(_ws_tls, 'scope', None)
     if _ws_scope is not None:
         key = (_stream_handle(), slot)
         buf = _ws_scope.get(key)
@@ -287,11 +287,12 @@ def workspace(nbytes, slot=0):
             buf = _ws_scope[key] = torch.empty(n, dtype=torch.uint8, device="cuda")
         return buf
     dev = (_stream_handle(), slot)   # one scratch per stream (stream handles are unique across devices)
+    if torch.cuda.is_current_stream_capturing():
+        # a hit is as wrong as a miss: the process-wide buffer would be baked into the graph and may be replaced (and freed) later
+        raise HipError("workspace(): called inside a hipGraph capture outside hip.capture_workspaces(...): the process-wide "
+                       "per-stream buffer would be baked into the graph and later freed by the cache")
     buf = _ws_cache.get(dev)
     if buf is None or buf.numel() < nbytes:
-        if torch.cuda.is_current_stream_capturing():
-            raise HipError("workspace(): allocation inside a hipGraph capture outside hip.capture_workspaces(...): the buffer "
-                           "would be baked into the graph and later freed by the process-wide cache")
         n = max(int(nbytes), 1 << 20)
         n = (n + (1 << 20) - 1) & ~((1 << 20) - 1)
         buf = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -300,6 +301,27 @@ def workspace(nbytes, slot=0):
 
 
 _const_stream = {}
+
+# Value-keyed device constants (gather index vectors, LSGAN target vectors: ops._idx_cache, networks._LossVectors) are cached for
+# the life of the process ONLY while a captured hipGraph may hold their addresses.  Without a capture (eager training with
+# varying colleague picks or a ramped loss weight) a cache clears itself at CONST_CACHE_MAX entries: a leak bound, not an LRU.
+# Kernels in flight on other streams may still read an evicted tensor (consumers do not record_stream on it), so the device is
+# drained first -- once per CONST_CACHE_MAX misses.
+CONST_CACHE_MAX = 4096
+_const_pinned = [False]
+
+
+def pin_const_caches():
+    """Called before the first hipGraph capture of the process: from here on the value-keyed constant caches never evict."""
+    _const_pinned[0] = True
+
+
+def const_cache_put(cache, key, value):
+    if not _const_pinned[0] and len(cache) >= CONST_CACHE_MAX:
+        torch.cuda.synchronize()
+        cache.clear()
+    cache[key] = value
+    return value
 
 
 def upload_const(host):

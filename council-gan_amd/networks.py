@@ -461,7 +461,7 @@ class _LossVectors:
         if v is None:
             # published only once the copies have completed: the module is called from more than one stream (hip.upload_const)
             v = (hip.upload_const(torch.tensor(tgt, dtype=torch.float32)), hip.upload_const(torch.tensor(wt, dtype=torch.float32)))
-            self._cache[key] = v
+            hip.const_cache_put(self._cache, key, v)
         return v
 
 

@@ -1575,9 +1575,10 @@ def _index_tensor(idx, device):
     key = (tuple(idx), str(device))
     t = _idx_cache.get(key)
     if t is None:
-        # entries are never dropped: captured hipGraphs hold the addresses (a few hundred bytes per distinct shape plan).
-        # The upload completes before the tensor is published -- the cache is read from every stream (hip.upload_const)
-        t = _idx_cache[key] = hip.upload_const(torch.tensor(list(idx), dtype=torch.int32))
+        # entries are never dropped once a hipGraph has been captured (graphs hold the addresses; a few hundred bytes per
+        # distinct shape plan), bounded otherwise (hip.const_cache_put).  The upload completes before the tensor is published
+        # -- the cache is read from every stream (hip.upload_const)
+        t = hip.const_cache_put(_idx_cache, key, hip.upload_const(torch.tensor(list(idx), dtype=torch.int32)))
     return t
 
 

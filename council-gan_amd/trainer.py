@@ -287,6 +287,12 @@ class Council_Trainer(nn.Module):
         dflt = '1' if ((self.shard.world_size > 1 and self.shard.dp == 1) or self.council_size == 1) else '0'
         self._graph_mode = str(self._hp_cfg.get('cg_graph', os.environ.get('CG_GRAPH', dflt))) == '1' and self.shard.dp == 1
         self._graph_warmup = max(1, int(os.environ.get('CG_GRAPH_WARMUP', '1')))
+        # captured graphs kept resident per segment kind (LRU).  Each keeps its private activation pool: 2 (the default) doubles
+        # the pools of a kind whose schedule flags alternate (council.flipOnOff) -- README "hipGraph mode"; parsed ONCE, here
+        try:
+            self._graph_keep = max(1, int(os.environ.get('CG_GRAPH_KEEP', '2')))
+        except ValueError:
+            raise ValueError("CG_GRAPH_KEEP must be a positive integer, got %r" % os.environ.get('CG_GRAPH_KEEP'))
         # replicas of a member: all-reduce the decoder's gradient bucket under the encoder's backward (CG_DP_OVERLAP=0: one
         # all-reduce of the whole flat gradient after the backward)
         self._dp_overlap = os.environ.get('CG_DP_OVERLAP', '1') != '0'
@@ -538,7 +544,7 @@ class Council_Trainer(nn.Module):
                 # instead of re-capturing at every flip); beyond that the least recently used one and the activation pool its
                 # graph owns are released -- after the device has drained, no replay of it may still be in flight
                 same = sorted((k for k in self._segs if k[0] == key[0]), key=lambda k: self._segs[k].used)
-                keep = max(1, int(os.environ.get('CG_GRAPH_KEEP', '2')))
+                keep = self._graph_keep
                 if len(same) >= keep:
                     torch.cuda.synchronize(self._device)
                     for k in same[:len(same) - keep + 1]:
@@ -547,7 +553,7 @@ class Council_Trainer(nn.Module):
                 seg = self._segs[key] = Segment()
             if seg.graph is not None and seg.generation != self._hin.generation:
                 seg.graph, seg.warm = None, 0                      # a static input buffer moved: capture again
-            if seg.graph is not None and seg.parents != self._iter_serials:
+            if not self._iter_eager and seg.graph is not None and seg.parents != self._iter_serials:
                 # the earlier segments of THIS iteration are not the captures this graph was recorded behind (one of them was
                 # re-captured or evicted since): the tensors it reads from their pools -- content codes, the repeated batch, the
                 # translations -- have moved.  Its warm-up has happened; capture again, behind the current ones.
@@ -586,6 +592,7 @@ class Council_Trainer(nn.Module):
                         # scratch buffers of the captured launches belong to THIS graph (hip.capture_workspaces: a buffer from
                         # the process-wide per-stream cache would be baked in and later freed under the graph)
                         seg.ws = {}
+                        hip.pin_const_caches()
                         with hip.capture_workspaces(seg.ws), \
                                 torch.cuda.graph(g, stream=cap, capture_error_mode=os.environ.get('CG_GRAPH_CAPTURE_MODE', 'thread_local')):
                             seg.out = body()

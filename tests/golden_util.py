@@ -94,3 +94,35 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = max(np.abs(b).max(), 1e-30)
     return float(np.abs(a - b).max() / den)
+
+
+# ---- generator-gradient statistic at the benchmark's shape (tests/golden/pin_gengrad_b4.npz, oracle/make_gengrad_golden.py) ----
+def gengrad_image_seed(seed):
+    """Seed of the synthetic batch of trainer seed `seed` (seed 1 -> 7: SURVEY.md 8d's batch, the one bench.py uses)."""
+    return 6 + seed
+
+
+def grad_subsample_index(name, numel):
+    """The fixed subsample of a gradient tensor both sides of the fixture use: sorted indices into the flattened tensor
+    (physical order of the state_dict tensor), >= 256 elements or 1 / 256 of it, whichever is larger, the whole tensor when it
+    is that small; drawn from a generator seeded by the tensor's name and size."""
+    import zlib
+    n_sub = min(numel, max(256, numel // 256))
+    if n_sub == numel:
+        return np.arange(numel)
+    rs = np.random.RandomState(zlib.crc32(("%s:%d" % (name, numel)).encode()) & 0x7fffffff)
+    return np.sort(rs.choice(numel, size=n_sub, replace=False))
+
+
+def subsample_l2rel(grads, names, numels, sub64, norm2_64):
+    """Estimator of || g - g64 || / || g64 || over all tensors of one generator from the subsample: every tensor's squared
+    error on its subsample is scaled by numel / subsample size; the denominator is the stored FULL norm."""
+    num, off = 0.0, 0
+    for n, numel in zip(names, numels):
+        idx = grad_subsample_index(str(n), int(numel))
+        ref = sub64[off:off + len(idx)].astype(np.float64)
+        off += len(idx)
+        got = np.asarray(grads[str(n)]).reshape(-1)[idx].astype(np.float64)
+        num += float(((got - ref) ** 2).sum()) * (int(numel) / len(idx))
+    assert off == len(sub64)
+    return float(np.sqrt(num) / max(np.sqrt(float(np.sum(norm2_64))), 1e-30))

@@ -12,12 +12,16 @@ Criteria (north star: within 1e-3 rel-fp32):
     every weight by ~lr = 1e-4 in the direction of its gradient's sign, so round-off-sized gradients flip steps in the
     reference too)."""
 import copy
+import os
 import random
 
 import numpy as np
 import torch
+import yaml
 
 from oracle import council_oracle as O
+
+CONFIGS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs")
 
 ACT_TOL = 1e-3
 # Generator gradients.  What separates two fp32-class evaluations of a generator gradient is a handful of DISCRETE events:
@@ -407,4 +411,62 @@ def gen_grad_ratios(cga, cfg, size, batch, seed=1, datapaths=("fp32", "split"), 
                   "ratio to it: %s | gen_total loss vs fp32 oracle %.1e"
                   % (report, dp, {"%s/%d" % k: "%.2e" % v[0] for k, v in out[dp].items()}, out['e_ref_run'],
                      {"%s/%d" % k: "%.2f" % v[2] for k, v in out[dp].items()}, out['loss_err'][dp]))
+    return out
+
+
+def gen_grad_statistic(cga, datapaths=("fp32", "split"), seeds=None, report=None):
+    """The generator-gradient criterion as a STATISTIC at the benchmark's own shape: for every seed of
+    tests/golden/pin_gengrad_b4.npz (male2female 256x256, council 4, batch 4; the fp32 oracle and its fp64 twin evaluated once in
+    the build container by oracle/make_gengrad_golden.py) one HIP iteration per datapath from the same weights, inputs and
+    host-RNG state; per (seed, member) err_ours = || g_ours - g64 || / || g64 || over all generator tensors (subsample estimator,
+    tests/golden_util.py) next to err_ref, the fp32 oracle's own.  Returns {'ref': {(seed, d, i): e}, dp: {(seed, d, i): e},
+    'loss_err': {dp: worst relative generator-loss error vs the fp32 oracle}}."""
+    import golden_util as GU
+    z = np.load(os.path.join(GU.GOLDEN_DIR, "pin_gengrad_b4.npz"))
+    cfg = yaml.safe_load(open(os.path.join(CONFIGS, "male2female_council_folder.yaml")))
+    cfg['council']['council_size'] = 4
+    cfg['iteration'] = 60000
+    cfg['batch_size'] = 4
+    cfg['new_size'] = cfg['crop_image_height'] = cfg['crop_image_width'] = 256
+    out = {'ref': {}, 'ref_full': {}, 'loss_err': {dp: 0.0 for dp in datapaths}}
+    for dp in datapaths:
+        out[dp] = {}
+    for seed in (seeds if seeds is not None else [int(s) for s in z["seeds"]]):
+        pre = "s%d/" % seed
+        for dp in datapaths:
+            c = copy.deepcopy(cfg)
+            c['cg_forward_precision'] = dp
+            O.seed_all(seed)
+            tr = cga.Council_Trainer(copy.deepcopy(c), 'cuda:0')
+            for d in tr._dirs:                     # the fixture was computed from THESE weights
+                for i, m in enumerate(tr._nets('gen', d)):
+                    sd = O.to_numpy_state(m.state_dict())
+                    sums = np.array([float(np.asarray(sd[n], dtype=np.float64).sum()) for n in sorted(sd)])
+                    np.testing.assert_allclose(sums, z[pre + "%s/%d/init_sum" % (d, i)], rtol=1e-9, atol=1e-9)
+            tr.cuda('cuda:0')
+            x_a, x_b = O.synthetic_batch(4, 256, seed=GU.gengrad_image_seed(seed))
+            tr.dis_update(x_a, x_b, c)
+            tr.dis_council_update(x_a, x_b, c)
+            tr.gen_update(x_a, x_b, c, c['iteration'])
+            torch.cuda.synchronize()
+            lv, ref = lossvec(tr.loss_gen_total_s), z[pre + "loss_gen_total"]
+            out['loss_err'][dp] = max(out['loss_err'][dp], float(np.max(np.abs(lv - ref) / np.maximum(np.abs(ref), 1e-7))))
+            for d in tr._dirs:
+                for i in range(tr.council_size):
+                    mp = pre + "%s/%d/" % (d, i)
+                    gs = grads_of(tr._nets('gen', d)[i])
+                    out[dp][(seed, d, i)] = GU.subsample_l2rel(gs, z[mp + "names"], z[mp + "numel"], z[mp + "sub64"], z[mp + "norm2_64"])
+                    out['ref'][(seed, d, i)] = float(z[mp + "err_ref_sub"])
+                    out['ref_full'][(seed, d, i)] = float(z[mp + "err_ref_full"])
+            del tr
+    if report is not None:
+        keys = sorted(out['ref'])
+        print("[%s] generator-gradient l2-rel error vs the fp64 oracle, per (seed, member); 'ref' = the fp32 oracle's own" % report)
+        print("  %-12s %10s %10s " % ("seed/member", "ref", "ref(full)") + " ".join("%10s" % dp for dp in datapaths))
+        for k in keys:
+            print("  %-12s %10.2e %10.2e " % ("%d/%s/%d" % k, out['ref'][k], out['ref_full'][k]) + " ".join("%10.2e" % out[dp][k] for dp in datapaths))
+        med = lambda v: float(np.median(list(v.values())))
+        print("  %-12s %10.2e %10.2e " % ("median", med(out['ref']), med(out['ref_full'])) + " ".join("%10.2e" % med(out[dp]) for dp in datapaths))
+        print("  %-12s %10.2e %10.2e " % ("max", max(out['ref'].values()), max(out['ref_full'].values())) + " ".join("%10.2e" % max(out[dp].values()) for dp in datapaths))
+        print("  gen_total loss vs the fp32 oracle (worst, relative):", {dp: "%.1e" % out['loss_err'][dp] for dp in datapaths})
     return out

@@ -84,22 +84,21 @@ def test_bench_batch_iteration_vs_fp32_oracle(cga):
 
 
 @pytest.mark.slow
-def test_bench_batch_generator_gradient_ratio(cga):
-    """the one quantity judged by a relaxed criterion -- the generator gradients -- AT THE BENCHMARK'S OWN
-    SHAPE (BASELINE.json configs[2]: 256x256, council 4, batch 4), with the fp64 twin: err(ours, fp64) / err(fp32 oracle, fp64)
-    per generator, on both datapaths from one evaluation of the oracles.  The survey's contract is 2 x: asserted
-    on the exact-fp32 datapath; the benchmarked split-precision datapath (22-bit products: more ReLU sign flips in the forward,
-    tests/parity_util.py) is held to 3 x.  The ratios are printed (README quotes them next to the throughput)."""
-    if os.environ.get("CG_LONG_ORACLE") != "1":
-        pytest.skip("opt-in (CG_LONG_ORACLE=1): the fp32 + fp64 oracles at batch 4 take ~6 minutes of HOST time, which would put the "
-                    "driver's `-m gpu` run next to its 20-minute limit; the round's run of it is profiles/r05_gengrad_ratio_b4.txt")
-    cfg = _cfg("male2female_council_folder.yaml", 4)
-    r = P.gen_grad_ratios(cga, cfg, 256, 4, seed=1, report="cfg3 256^2 council 4 B4")
+def test_bench_batch_generator_gradient_statistic(cga):
+    """The one quantity judged by a relaxed criterion -- the generator gradients -- AT THE BENCHMARK'S OWN SHAPE (BASELINE.json
+    configs[2]: 256x256, council 4, batch 4) as a STATISTIC over seeds {1, 2, 3} x 4 members = 12 draws: per
+    (seed, member) err_ours and err_ref (the fp32 oracle's own error) against the fp64 oracle, whose side is the committed
+    fixture tests/golden/pin_gengrad_b4.npz (oracle/make_gengrad_golden.py), so this costs two HIP iterations per seed.
+    SURVEY.md 7 / 8c: err(ours) <= 2 x err(ref32) -- asserted on the MEDIAN and on the MAXIMUM over the 12 draws on the exact-fp32
+    datapath; the benchmarked split-precision datapath (22-bit products) is held to 3 x.  The table is printed per member."""
+    r = P.gen_grad_statistic(cga, report="cfg3 256^2 council 4 B4, seeds 1-3")
+    assert len(r['ref']) >= 12
     assert r['loss_err']['fp32'] <= 1e-3 and r['loss_err']['split'] <= 1e-3, r['loss_err']
-    worst32 = max(v[2] for v in r['fp32'].values())
-    worst_split = max(v[2] for v in r['split'].values())
-    assert worst32 <= 2.0, ("exact-fp32 datapath: generator-gradient error above 2 x the reference arithmetic's own gap", r['fp32'])
-    assert worst_split <= 3.0, ("split datapath: generator-gradient error above 3 x the reference arithmetic's own gap", r['split'])
+    ref = np.array(list(r['ref'].values()))
+    for dp, factor in (("fp32", 2.0), ("split", 3.0)):
+        ours = np.array([r[dp][k] for k in r['ref']])
+        assert np.median(ours) <= factor * np.median(ref), (dp, "median", float(np.median(ours)), float(np.median(ref)))
+        assert ours.max() <= factor * ref.max(), (dp, "max", float(ours.max()), float(ref.max()))
 
 
 def test_cfg2_iteration_vs_oracle(cga):

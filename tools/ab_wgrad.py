@@ -30,7 +30,7 @@ SHAPES = [
 
 
 def operands(lib, G, N, H, W, Cin, Cout, K, stride, pad):
-    g = ops.fwd_geom(N, H, W, Cin, 0, 0, K, K, stride, pad, Cout, 0)
+    g = ops.fwd_geom(G * N, H, W, Cin, 0, 0, K, K, stride, pad, Cout, 0)      # the geometry's batch is the whole launch: G members x N samples
     x = torch.randn(G * N, Cin, H, W, device="cuda").contiguous(memory_format=CL)
     dz = (torch.randn(G * N, Cout, g.Ho, g.Wo, device="cuda") * 1e-3).contiguous(memory_format=CL)
     with torch.no_grad():
