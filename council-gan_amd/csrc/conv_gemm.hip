@@ -1564,6 +1564,7 @@ static void tuning_from_env() {
     t.wgrad_x3_multitap = env_int("CG_WGRAD_X3_MULTITAP", 1) != 0;
     t.x3_cls_minor = env_int("CG_X3_CLS_MINOR", 1) != 0;
     t.x3_generic_epilogue = env_int("CG_X3_GENERIC_EPILOGUE", 0) != 0;
+    t.wgrad_xcd_group = env_int("CG_WGRAD_XCD_GROUP", 1) != 0;
     g_tune = t;
 }
 static cg_tuning& tune() {
@@ -2420,7 +2421,7 @@ int launch_wgrad_x3t(const cg_conv_geom* g, const WgradPlan& p, const void* xs, 
     ProfScope prof(7, BM, BN, true, 2.0 * (double)M * nmember * (double)g->Cout * (double)K, st, g, nmember);
     hipLaunchKernelGGL((conv_wgrad_x3t_kernel<BM, BN, WM, WN>), grid, block, 0, st, *g, xs, (unsigned)x3_span(x_lo, x_plane),
                        x_scale, dzs, (unsigned)x3_span(dz_lo, dz_plane), dz_scale, out, M, K, p.tiles_n, p.slices_per_split,
-                       want_bias, ilog2_exact(g->Ho * g->Wo), ilog2_exact(g->Wo));
+                       want_bias, ilog2_exact(g->Ho * g->Wo), ilog2_exact(g->Wo), tune().wgrad_xcd_group);
     CG_LAUNCH_CHECK("conv_wgrad_x3t_kernel");
     return CG_OK;
 }
@@ -2432,7 +2433,7 @@ int launch_wgrad_x3tw(const cg_conv_geom* g, const WgradPlan& p, const void* xs,
     ProfScope prof(7, 256, 256, true, 2.0 * (double)M * nmember * (double)g->Cout * (double)K, st, g, nmember);
     hipLaunchKernelGGL((conv_wgrad_x3tw_kernel<256, 256, 128, 64, 1>), grid, block, 0, st, *g, xs, (unsigned)x3_span(x_lo, x_plane),
                        x_scale, dzs, (unsigned)x3_span(dz_lo, dz_plane), dz_scale, out, M, K, p.tiles_n, p.slices_per_split,
-                       want_bias, ilog2_exact(g->Ho * g->Wo), ilog2_exact(g->Wo));
+                       want_bias, ilog2_exact(g->Ho * g->Wo), ilog2_exact(g->Wo), tune().wgrad_xcd_group);
     CG_LAUNCH_CHECK("conv_wgrad_x3tw_kernel");
     return CG_OK;
 }

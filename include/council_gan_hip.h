@@ -322,7 +322,10 @@ typedef struct cg_tuning {
     int32_t x3_generic_epilogue; /* CG_X3_GENERIC_EPILOGUE (0): A/B switch -- 1 = the split-precision forward / data-gradient kernels always take
                               * the generic copy of their epilogue value loop (round 4's code path) instead of the copies compiled for
                               * {no activation, LeakyReLU} x {with, without statistics}; results are bit-identical either way */
-    int32_t reserved[2];
+    int32_t wgrad_xcd_group; /* CG_WGRAD_XCD_GROUP (1): split-precision weight-gradient grids order their blocks so that the tap tiles of one
+                              * (member, position range) -- which stream the same dz rows and overlapping x rows -- run on ONE XCD and meet in
+                              * its L2 instead of being dealt round-robin over all eight (bit-identical results) */
+    int32_t reserved[1];
 } cg_tuning;
 int cg_tuning_get(cg_tuning* out);
 int cg_tuning_set(const cg_tuning* in);

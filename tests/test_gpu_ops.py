@@ -768,7 +768,7 @@ def _wgrad_tile_case(cga, shape, switch, restore):
                 assert rel(wide[n][m][0], base[n][m][0]) < 2e-6
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 60, 64, 67, 68])
 def test_split_precision_forward_every_tile_configuration(cga, cfg):
     """Every tile configuration of conv_fwd_x3_kernel the library ships, forced explicitly, on a shape whose row count
     (960) and channel count (160) are multiples of no tile edge, with bias + LeakyReLU in the epilogue."""

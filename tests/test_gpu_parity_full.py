@@ -83,22 +83,34 @@ def test_bench_batch_iteration_vs_fp32_oracle(cga):
     assert "loss/disc_total" in errs and any(k[0] == "grad" and k[1] == "disc" for k in errs if not isinstance(k, str))
 
 
+def _gen_grad_statistic(cga, dp, factor):
+    r = P.gen_grad_statistic(cga, datapaths=(dp,), report="cfg3 256^2 council 4 B4, seeds 1-3, datapath " + dp)
+    assert len(r['ref']) >= 12
+    assert r['loss_err'][dp] <= 1e-3, r['loss_err']
+    ref = np.array(list(r['ref'].values()))
+    ours = np.array([r[dp][k] for k in r['ref']])
+    return float(np.median(ours)), float(np.median(ref)), float(ours.max()), float(ref.max()), factor
+
+
 @pytest.mark.slow
 def test_bench_batch_generator_gradient_statistic(cga):
     """The one quantity judged by a relaxed criterion -- the generator gradients -- AT THE BENCHMARK'S OWN SHAPE (BASELINE.json
-    configs[2]: 256x256, council 4, batch 4) as a STATISTIC over seeds {1, 2, 3} x 4 members = 12 draws: per
-    (seed, member) err_ours and err_ref (the fp32 oracle's own error) against the fp64 oracle, whose side is the committed
-    fixture tests/golden/pin_gengrad_b4.npz (oracle/make_gengrad_golden.py), so this costs two HIP iterations per seed.
-    SURVEY.md 7 / 8c: err(ours) <= 2 x err(ref32) -- asserted on the MEDIAN and on the MAXIMUM over the 12 draws on the exact-fp32
-    datapath; the benchmarked split-precision datapath (22-bit products) is held to 3 x.  The table is printed per member."""
-    r = P.gen_grad_statistic(cga, report="cfg3 256^2 council 4 B4, seeds 1-3")
-    assert len(r['ref']) >= 12
-    assert r['loss_err']['fp32'] <= 1e-3 and r['loss_err']['split'] <= 1e-3, r['loss_err']
-    ref = np.array(list(r['ref'].values()))
-    for dp, factor in (("fp32", 2.0), ("split", 3.0)):
-        ours = np.array([r[dp][k] for k in r['ref']])
-        assert np.median(ours) <= factor * np.median(ref), (dp, "median", float(np.median(ours)), float(np.median(ref)))
-        assert ours.max() <= factor * ref.max(), (dp, "max", float(ours.max()), float(ref.max()))
+    configs[2]: 256x256, council 4, batch 4) ON THE BENCHMARKED (split-precision) DATAPATH, as a STATISTIC over seeds {1, 2, 3} x 4
+    members = 12 draws: per (seed, member) err_ours and err_ref (the fp32 oracle's own error) against the fp64
+    oracle, whose side is the committed fixture tests/golden/pin_gengrad_b4.npz (oracle/make_gengrad_golden.py) -- one HIP iteration
+    per seed.  Asserted: median(ours) <= 3 x median(ref) and max(ours) <= 3 x max(ref) over the 12 draws (the survey's contract is 2 x
+    on the reference's own arithmetic; 22-bit products get 3 x).  The per-member table is printed (README quotes it)."""
+    med, med_ref, mx, mx_ref, f = _gen_grad_statistic(cga, "split", 3.0)
+    assert med <= f * med_ref, ("split", "median", med, med_ref)
+    assert mx <= f * mx_ref, ("split", "max", mx, mx_ref)
+
+
+@pytest.mark.slow
+def test_bench_batch_generator_gradient_statistic_exact_fp32(cga):
+    """The same statistic on the exact-fp32-MFMA datapath (cg_forward_precision: fp32) against the survey's 2 x."""
+    med, med_ref, mx, mx_ref, f = _gen_grad_statistic(cga, "fp32", 2.0)
+    assert med <= f * med_ref, ("fp32", "median", med, med_ref)
+    assert mx <= f * mx_ref, ("fp32", "max", mx, mx_ref)
 
 
 def test_cfg2_iteration_vs_oracle(cga):

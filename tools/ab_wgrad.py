@@ -1,7 +1,7 @@
 """Split-precision weight gradient, one launch shape at a time: time per launch under the library's tile choices (A/B through
 the cg_tuning switches), or a plain launch loop for a rocprofv3 --pmc pass.
 
-    python tools/ab_wgrad.py [shape indices]                 table: default | bm256 off | wide off  (max difference vs default)
+    python tools/ab_wgrad.py [shape indices]                 table: default | XCD grouping off | bm256 off | wide off  (max difference vs default)
     python tools/ab_wgrad.py --launch <shape index> [reps]   `reps` launches of one shape (PMC_KERNEL=conv_wgrad PMC_TOOL=... tools/prof_bench.sh)
 
 Shapes are the member-batched launches of the bench step (profiles/r05_final_conv_shapes.txt, family f7): G members x N samples."""
@@ -77,20 +77,17 @@ def main():
         print("wgrad", SHAPES[si][0], "done; %.1f GFLOP per launch" % (flops / 1e9))
         return
     shapes = [int(i) for i in sys.argv[1].split(",")] if len(sys.argv) > 1 else list(range(len(SHAPES)))
-    modes = [("default", None), ("bm256=0", ("cg_conv2d_wgrad_x3_bm256", 0, 2)), ("wide=0", ("cg_conv2d_wgrad_x3_wide", 0, 2))]
+    modes = [("default", {}), ("xcd_group=0", {"wgrad_xcd_group": 0}), ("bm256=0", {"wgrad_x3_bm256": 0}), ("wide=0", {"wgrad_x3_wide": 0})]
     print("%-34s | " % "shape" + " ".join("%24s" % m[0] for m in modes))
     for si in shapes:
         run, dw, flops = operands(lib, *SHAPES[si][1:])
         reps = min(50, max(3, int(2e11 / flops / 4)))
         ref, cells = None, []
-        for name, sw in modes:
-            if sw:
-                getattr(lib, sw[0])(sw[1])
-            t = timeit(run, reps)
-            torch.cuda.synchronize()
-            out = dw.clone()
-            if sw:
-                getattr(lib, sw[0])(sw[2])
+        for name, fields in modes:
+            with hip.tuned(**fields):
+                t = timeit(run, reps)
+                torch.cuda.synchronize()
+                out = dw.clone()
             ref = out if ref is None else ref
             cells.append("%7.1fus %4.0fTF d%.0e" % (t * 1000, flops / t / 1e9, float((out - ref).abs().max() / ref.abs().max())))
         print("%-34s | " % SHAPES[si][0] + " ".join("%24s" % c for c in cells), flush=True)

@@ -79,7 +79,7 @@ def main():
     if sys.argv[1] == "--launch":
         return launch_loop(sys.argv[2:])
     cfgs = [int(c) for c in sys.argv[1].split(",")]
-    shapes = [int(i) for i in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4, 13, 14]
+    shapes = [int(i) for i in sys.argv[2].split(",") if i != "-"] if len(sys.argv) > 2 else [0, 1, 2, 3, 4, 13, 14]      # "-": EXTRA_SHAPES only
     table = list(SHAPES)
     for spec in filter(None, os.environ.get("EXTRA_SHAPES", "").split(";")):     # name,N,H,W,Cin,Cout,K,stride,pad,up
         f = spec.split(",")

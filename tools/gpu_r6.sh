@@ -18,6 +18,9 @@ for st in "$@"; do
     tiles)   run tiles 300 python -m pytest tests/test_gpu_ops.py -q -x -p no:cacheprovider -k "tile_configuration" ;;
     ops)     run ops 400 python -m pytest tests/test_gpu_ops.py -q -x -p no:cacheprovider ;;
     ab4w)    EXTRA_SHAPES="res16,16,64,64,256,256,3,1,1,0;res32,32,64,64,256,256,3,1,1,0;dc128_256,16,128,128,128,256,4,2,1,0" run ab4w 300 python tools/ab_x3.py 16,50,51,52 0; cat $O/ab4w.log | cut -c1-200 ;;
+    abr64)   EXTRA_SHAPES="c64_3x3_256,16,256,256,64,64,3,1,1,0;c64_1x1_256,16,256,256,64,64,1,1,0,0;up128x4_64_128,16,128,128,128,64,2,1,0,0;c64_3x3_128_b8,8,128,128,64,64,3,1,1,0;c64_3x3_256_b4,4,256,256,64,64,3,1,1,0" run abr64 300 python tools/ab_x3.py 2,26,60,61,62,63,67 -; cat $O/abr64.log | cut -c1-260 ;;
+    abr128)  EXTRA_SHAPES="c128_3x3_128,16,128,128,128,128,3,1,1,0;dg256x4_128_64,16,64,64,256,128,2,1,0,0;c64_128_4x4s2_256,16,256,256,64,128,4,2,1,0;c128_3x3_128_b4,4,128,128,128,128,3,1,1,0;d64_128_4x4s2_128_b32,32,128,128,64,128,4,2,1,0" run abr128 300 python tools/ab_x3.py 13,1,17,64,65,66,68 -; cat $O/abr128.log | cut -c1-260 ;;
+    abk128)  EXTRA_SHAPES="c128_3x3_128,16,128,128,128,128,3,1,1,0;dg256x4_128_64,16,64,64,256,128,2,1,0,0;c64_128_4x4s2_256,16,256,256,64,128,4,2,1,0;d64_128_4x4s2_128_b32,32,128,128,64,128,4,2,1,0;dg512x4_256_32,16,32,32,512,256,2,1,0,0" run abk128 300 python tools/ab_x3.py 13,23,1,24 -; cat $O/abk128.log | cut -c1-200 ;;
     probe4w) run probe4w 200 python tools/probe_x3w_stalls.py 16 53 4; tail -40 $O/probe4w.log | cut -c1-160 ;;
     abwg)    run abwg 300 python tools/ab_wgrad.py; cat $O/abwg.log | cut -c1-200 ;;
     pmc1)    pmc x3_128x64 conv_fwd_x3_kernel 2 "c64,16,256,256,64,64,3,1,1,0" ;;
