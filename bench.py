@@ -673,6 +673,20 @@ def main():
                                      "steps": n32, "warmup": 2, "dtype": "f32 (v_mfma_f32_32x32x2_f32 everywhere)",
                                      "step_achieved": round(wmin / (ms32 / 1000.0), 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                      "step_frac": round(wmin / (ms32 / 1000.0) / FP32_MFMA_PEAK_TFLOPS, 4)}
+                out["exact_fp32"]["summation"] = ("chunked: the K range of a convolution is summed in chunks of four K-slices (cg_tuning."
+                                                  "fp32_chunked_sum = 1, the default: ~3.7x less accumulation round-off than one chain of "
+                                                  "K/2 dependent MFMAs; generator-gradient statistic at the reference arithmetic's level)")
+                try:
+                    # the same leg with ONE accumulation chain per output (rounds 1-5 arithmetic, CG_FP32_CHUNKED_SUM=0): faster tiles
+                    # (two 128x128 blocks per CU), 2.6x the reference kernels' forward round-off -- timed in the same run for the record
+                    with cga.hip.tuned(fp32_chunked_sum=0):
+                        el1 = time_steps(step32, fence, 2, n32, first=n32 + 4)
+                    ms1 = 1000.0 * el1 / n32
+                    out["exact_fp32"]["single_chain"] = {"value": round(args.batch * n32 / el1, 4), "ms_per_step": round(ms1, 3),
+                                                         "step_achieved": round(wmin / (ms1 / 1000.0), 2),
+                                                         "step_frac": round(wmin / (ms1 / 1000.0) / FP32_MFMA_PEAK_TFLOPS, 4)}
+                except Exception as e:      # noqa: BLE001
+                    out["exact_fp32"]["single_chain"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
                 if not args.no_kernel_profile:
                     # the same per-kernel evidence as the headline leg: HIP events around every MFMA conv launch of one serialised iteration
                     prof32, err32 = kernel_profile(cga, tr32, lambda: step32(n32 + 2))

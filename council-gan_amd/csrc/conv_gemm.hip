@@ -397,8 +397,17 @@ __global__ __launch_bounds__(512) void conv_fwd_thin_kernel(
         const float v = wl[(wn * 32 + l31) * KS + (kp / JP) * RL + j];   // j == RL (padded pair) reads the next k / the pad word
         breg[kp] = j < RL ? v : 0.f;
     }
-    const float bj = bias ? bias[wn * 32 + l31] : 0.f;
-    cg_touch(bj);
+    // this lane's 16 output channels: wn * 32 + 8 q + 4 lh + {0..3}, q = 0..3 (the D rows of its half-wave)
+    float4 bj4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float* bq = bias + wn * 32 + 8 * q + 4 * lh;      // (scalar loads: a pool-resident bias is only 4-byte aligned)
+        bj4[q] = bias ? make_float4(bq[0], bq[1], bq[2], bq[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        cg_touch(bj4[q].x);
+        cg_touch(bj4[q].y);
+        cg_touch(bj4[q].z);
+        cg_touch(bj4[q].w);
+    }
 
     // LDS offsets of this lane's two A rows: row r of the tile is pixel (r / 16, r % 16)
     int rb[2];
@@ -473,21 +482,30 @@ __global__ __launch_bounds__(512) void conv_fwd_thin_kernel(
                 a0[kp % DEPTH] = pt[rb[0] + off];
                 a1[kp % DEPTH] = pt[rb[1] + off];
             }
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(u0, breg[kp], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(u1, breg[kp], acc1, 0, 0, 0);
+            // operands SWAPPED (round 6): the weights are the MFMA's A operand (rows of D = output channels), the patch elements its B
+            // operand (columns of D = pixels) -- the same products in the same order, but the D layout then gives every lane ONE pixel
+            // and, per four registers, FOUR CONSECUTIVE channels: the epilogue stores 16 bytes per lane (8 dwordx4 per tile and lane
+            // instead of 32 dword stores), which is what a kernel that writes 256 bytes per 54-MFMA pixel needs
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(breg[kp], u0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(breg[kp], u1, acc1, 0, 0, 0);
         }
 
-        // C/D layout of the 32x32 MFMA: col = lane % 32, row = (r & 3) + 8 * (r >> 2) + 4 * (lane / 32)
+        // C/D layout of the 32x32 MFMA: col = lane % 32 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane / 32) (channel)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + l31;
+            const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+            if (oy < g.Ho && ox < g.Wo) {
+                float* __restrict__ dst = y + (((size_t)n * g.Ho + oy) * g.Wo + ox) * BN + wn * 32 + 4 * lh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
-                if (oy < g.Ho && ox < g.Wo) {
-                    const float v = cg_apply_act((i ? acc1[r] : acc0[r]) + bj, g.act);
-                    y[(((size_t)n * g.Ho + oy) * g.Wo + ox) * BN + wn * 32 + l31] = v;
-                    vmax = fmaxf(vmax, fabsf(v));
+                for (int q = 0; q < 4; ++q) {
+                    float4 v;
+                    v.x = cg_apply_act((i ? acc1[4 * q + 0] : acc0[4 * q + 0]) + bj4[q].x, g.act);
+                    v.y = cg_apply_act((i ? acc1[4 * q + 1] : acc0[4 * q + 1]) + bj4[q].y, g.act);
+                    v.z = cg_apply_act((i ? acc1[4 * q + 2] : acc0[4 * q + 2]) + bj4[q].z, g.act);
+                    v.w = cg_apply_act((i ? acc1[4 * q + 3] : acc0[4 * q + 3]) + bj4[q].w, g.act);
+                    *reinterpret_cast<float4*>(dst + 8 * q) = v;
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 }
             }
         }
@@ -690,7 +708,13 @@ __device__ __forceinline__ void dbg_stamp(int tile, int slot) {
     }
 }  // >= num_records of any tensor validate_geom lets through here
 
-template <int BM, int BN, int WM, int WN, int PF, int ABL>
+// FOLD > 0 ("chunked sum", round 6): the accumulator is folded into a second register set every FOLD K-slices.  v_mfma_f32_32x32x2_f32
+// rounds once per TWO products, so a K = 2304 contraction is a chain of 1152 dependent fp32 roundings -- a random walk of ~sqrt(K/2)
+// half-ulps, 2.6x the round-off of the reference's CPU kernels (16-lane FMA chains of K/16) and the reason this datapath drew more
+// ReLU / focus-loss sign flips than the reference arithmetic in the generator-gradient statistic.  Summing
+// chunks of FOLD x 16 MFMAs first and the chunk sums afterwards shortens both chains (blocked summation): for FOLD = 4 the expected
+// round-off drops ~3.7x -- below the CPU kernels'.  Costs TM x TN x 16 registers and one v_add per accumulator value and chunk.
+template <int BM, int BN, int WM, int WN, int PF, int ABL, int FOLD = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kernel(
     PipeBatch batch, const float* __restrict__ x1, const float* __restrict__ bias, float* __restrict__ y,
     unsigned x_bytes, double* __restrict__ stats, Members mb) {
@@ -897,19 +921,46 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kern
         mma(a1, b1);
         group_order();
     };
+    f32x16 tot[FOLD ? TM : 1][FOLD ? TN : 1];
+    if constexpr (FOLD > 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+    }
+    auto fold = [&](bool last) {
+        if constexpr (FOLD > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float t = tot[i][j][r] + acc[i][j][r];
+                        tot[i][j][r] = t;
+                        acc[i][j][r] = last ? t : 0.f;       // the epilogue reads acc
+                    }
+        }
+    };
+    static_assert(FOLD == 0 || FOLD == 4, "chunks of four K-slices");
     if (ABL != 2 && NW >= 8 && wid >= NW / 2) {
         for (int kt = 0; kt + 1 < nk; kt += 2) {
             slice(I0(), I1());
             slice(I1(), I1());
+            if (FOLD > 0 && (kt & 2)) fold(false);      // every second pair of slices
         }
         if (nk & 1) slice(I0(), I1());
     } else {
         for (int kt = 0; kt + 1 < nk; kt += 2) {
             slice(I0(), I0());
             slice(I1(), I0());
+            if (FOLD > 0 && (kt & 2)) fold(false);
         }
         if (nk & 1) slice(I0(), I0());
     }
+    fold(true);
     if constexpr (ABL == 3) dbg_stamp(tile, 2);
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -1565,6 +1616,7 @@ static void tuning_from_env() {
     t.x3_cls_minor = env_int("CG_X3_CLS_MINOR", 1) != 0;
     t.x3_generic_epilogue = env_int("CG_X3_GENERIC_EPILOGUE", 0) != 0;
     t.wgrad_xcd_group = env_int("CG_WGRAD_XCD_GROUP", 1) != 0;
+    t.fp32_chunked_sum = env_int("CG_FP32_CHUNKED_SUM", 1) != 0;
     g_tune = t;
 }
 static cg_tuning& tune() {
@@ -1651,7 +1703,13 @@ int launch_pipe_batch(PipeBatch& b, int ncls, const float* x1, const float* bias
     for (int c = ncls; c < 4; ++c) b.c[c].ntiles = 0;
     dim3 grid(max_tiles, ncls, mb.n), block(NT);
     ProfScope prof(2, BM, BN, true, flops, st, &b.c[0].g, ncls * mb.n);
-    hipLaunchKernelGGL((conv_fwd_pipe_kernel<BM, BN, WM, WN, PF, ABL>), grid, block, 0, st, b, x1, bias, y, x_bytes, stats, mb);
+    // (the chunked-sum variant of the 128 x 128 / 8-wave tile needs 142 registers -- one block per CU instead of two -- and takes the
+    // two-slice prefetch distance to cover for the lost occupancy; held to 128 registers it spills 96 and is slower still)
+    constexpr int PFF = (BM == 128 && BN == 128 && WN == 32 && PF == 1 && ABL == 0) ? 2 : PF;
+    if (ABL == 0 && tune().fp32_chunked_sum)
+        hipLaunchKernelGGL((conv_fwd_pipe_kernel<BM, BN, WM, WN, PFF, ABL, ABL == 0 ? 4 : 0>), grid, block, 0, st, b, x1, bias, y, x_bytes, stats, mb);
+    else
+        hipLaunchKernelGGL((conv_fwd_pipe_kernel<BM, BN, WM, WN, PF, ABL>), grid, block, 0, st, b, x1, bias, y, x_bytes, stats, mb);
     CG_LAUNCH_CHECK("conv_fwd_pipe_kernel");
     return CG_OK;
 }
@@ -1845,6 +1903,9 @@ int pick_fwd_cfg(const cg_conv_geom* g, long M, bool pipe) {
     M *= tune().tile_rows_scale;      // test hook: choose tiles as if the launch had k x the rows (cg_tuning.tile_rows_scale)
     const long blocks128 = ((M + 127) / 128) * ((g->Cout + 127) / 128);
     if (g->Cout > 64) {
+        // chunked sums (cg_tuning.fp32_chunked_sum) cost the 128 x 128 / 8-wave tile its second block per CU (142 registers); the
+        // 256 x 128 tile of 64 x 64 wave tiles runs one block per CU either way, so launches that fill the chip with it take it
+        if (pipe && tune().fp32_chunked_sum && ((M + 255) / 256) * ((g->Cout + 127) / 128) >= 256) return 24;
         if (blocks128 >= 192) return pipe ? 20 : 6;
         if (pipe) return 23;
         return blocks128 < 96 ? 10 : 3;

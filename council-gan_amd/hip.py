@@ -42,7 +42,7 @@ class Tuning(ctypes.Structure):
     """cg_tuning: the library's kernel-selection table (its only process-wide state)."""
     _fields_ = [(n, c_int32) for n in ("fwd_thin", "wgrad_thin", "wgrad_x3_bm256", "wgrad_x3_wide", "wgrad_x3_perm",
                                        "wgrad_legacy", "x3_wide", "x3_thin_out", "x3_korder", "tile_rows_scale",
-                                       "no_amax_atomic", "wgrad_x3_multitap", "x3_cls_minor", "x3_generic_epilogue", "wgrad_xcd_group")] + [("reserved", c_int32 * 1)]
+                                       "no_amax_atomic", "wgrad_x3_multitap", "x3_cls_minor", "x3_generic_epilogue", "wgrad_xcd_group", "fp32_chunked_sum")]
 
 
 class HipLibraryMissing(RuntimeError):

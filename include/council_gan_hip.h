@@ -325,7 +325,9 @@ typedef struct cg_tuning {
     int32_t wgrad_xcd_group; /* CG_WGRAD_XCD_GROUP (1): split-precision weight-gradient grids order their blocks so that the tap tiles of one
                               * (member, position range) -- which stream the same dz rows and overlapping x rows -- run on ONE XCD and meet in
                               * its L2 instead of being dealt round-robin over all eight (bit-identical results) */
-    int32_t reserved[1];
+    int32_t fp32_chunked_sum; /* CG_FP32_CHUNKED_SUM (1): the exact-fp32 forward / data-gradient kernel sums its K range in chunks of four
+                              * K-slices (blocked summation: ~3.7x less accumulation round-off than one chain of K/2 MFMAs); 0 = one chain
+                              * (round 1-5 arithmetic).  Changes the last bits of fp32-datapath results, nothing else */
 } cg_tuning;
 int cg_tuning_get(cg_tuning* out);
 int cg_tuning_set(const cg_tuning* in);

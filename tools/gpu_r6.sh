@@ -21,6 +21,17 @@ for st in "$@"; do
     abr64)   EXTRA_SHAPES="c64_3x3_256,16,256,256,64,64,3,1,1,0;c64_1x1_256,16,256,256,64,64,1,1,0,0;up128x4_64_128,16,128,128,128,64,2,1,0,0;c64_3x3_128_b8,8,128,128,64,64,3,1,1,0;c64_3x3_256_b4,4,256,256,64,64,3,1,1,0" run abr64 300 python tools/ab_x3.py 2,26,60,61,62,63,67 -; cat $O/abr64.log | cut -c1-260 ;;
     abr128)  EXTRA_SHAPES="c128_3x3_128,16,128,128,128,128,3,1,1,0;dg256x4_128_64,16,64,64,256,128,2,1,0,0;c64_128_4x4s2_256,16,256,256,64,128,4,2,1,0;c128_3x3_128_b4,4,128,128,128,128,3,1,1,0;d64_128_4x4s2_128_b32,32,128,128,64,128,4,2,1,0" run abr128 300 python tools/ab_x3.py 13,1,17,64,65,66,68 -; cat $O/abr128.log | cut -c1-260 ;;
     abk128)  EXTRA_SHAPES="c128_3x3_128,16,128,128,128,128,3,1,1,0;dg256x4_128_64,16,64,64,256,128,2,1,0,0;c64_128_4x4s2_256,16,256,256,64,128,4,2,1,0;d64_128_4x4s2_128_b32,32,128,128,64,128,4,2,1,0;dg512x4_256_32,16,32,32,512,256,2,1,0,0" run abk128 300 python tools/ab_x3.py 13,23,1,24 -; cat $O/abk128.log | cut -c1-200 ;;
+    abc64)   EXTRA_SHAPES="c64_3x3_256,16,256,256,64,64,3,1,1,0;c64_1x1_256,16,256,256,64,64,1,1,0,0;up128x4_64_128,16,128,128,128,64,2,1,0,0;c64_3x3_256_b4,4,256,256,64,64,3,1,1,0" run abc64 300 python tools/ab_x3.py 2,25,69,70,26,27 -; cat $O/abc64.log | cut -c1-230 ;;
+    exact)   run exact_on 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-other-configs; CG_FP32_CHUNKED_SUM=0 run exact_off 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-other-configs; for f in exact_on exact_off; do python - $O/$f.log <<'PY'
+import json,sys
+p=[json.loads(l) for l in open(sys.argv[1]) if l.startswith('{')][-1]; e=p['exact_fp32']
+print(sys.argv[1].split('/')[-1], 'split', p['ms_per_step'], 'exact_fp32', e['ms_per_step'], e['step_frac'], e.get('kernel'), e.get('kernel_avg_us'), e.get('all_conv_kernels_tflops'))
+PY
+done ;;
+    stat32)  run stat32 600 python -m pytest tests/test_gpu_parity_full.py -x -q -s -p no:cacheprovider -k "statistic_exact_fp32"; grep -A20 "generator-gradient l2-rel" $O/stat32.log | cut -c1-110; tail -3 $O/stat32.log ;;
+    abgroup) bash tools/ab_step.sh ${O#gpurun_out/}/abgroup "new" "nogroup:CG_WGRAD_XCD_GROUP=0" 2>&1 | tee $O/abgroup.log ;;
+    abbound) bash tools/ab_step.sh ${O#gpurun_out/}/abbound "new" "bounded:CG_BOUNDED_SPLIT=1" "fused:CG_BOUNDED_SPLIT=1 CG_FUSED_ACT_BWD=1" 2>&1 | tee $O/abbound.log ;;
+    ab5)     EXTRA_SHAPES="c128_3x3_128,16,128,128,128,128,3,1,1,0;dg256x4_128_64,16,64,64,256,128,2,1,0,0;c64_128_4x4s2_256,16,256,256,64,128,4,2,1,0;d64_128_4x4s2_128_b32,32,128,128,64,128,4,2,1,0" run ab5 300 python tools/ab_x3.py 13,5,1,0 -; cat $O/ab5.log | cut -c1-200 ;;
     probe4w) run probe4w 200 python tools/probe_x3w_stalls.py 16 53 4; tail -40 $O/probe4w.log | cut -c1-160 ;;
     abwg)    run abwg 300 python tools/ab_wgrad.py; cat $O/abwg.log | cut -c1-200 ;;
     pmc1)    pmc x3_128x64 conv_fwd_x3_kernel 2 "c64,16,256,256,64,64,3,1,1,0" ;;
