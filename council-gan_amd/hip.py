@@ -243,7 +243,11 @@ _PTR_DTYPES = frozenset((torch.float32, torch.int32, torch.uint8, torch.float16)
 
 
 _ws_cache = {}
-_ws_tls = threading.local()      # .scope: the workspace table of the hipGraph capture in progress ON THIS THREAD (capture_workspaces), or absent
+# The workspace table of the hipGraph capture in progress (capture_workspaces), or None.  Process-wide ON PURPOSE: the backward of a
+# captured segment runs on autograd's worker threads, which must see the capturing thread's table (a thread-local made every
+# backward workspace() call of a capture raise and the trainer fall back to eager execution); captures on two host threads at once
+# are not supported (the trainer is single-threaded, like the reference).
+_ws_scope = [None]
 
 
 class capture_workspaces:
@@ -263,11 +267,11 @@ class capture_workspaces:
         self.table = table
 
     def __enter__(self):
-        self.prev, _ws_tls.scope = getattr(_ws_tls, 'scope', None), self.table
+        self.prev, _ws_scope[0] = _ws_scope[0], self.table
         return self.table
 
     def __exit__(self, *exc):
-        _ws_tls.scope = self.prev
+        _ws_scope[0] = self.prev
         return False
 
 
@@ -276,15 +280,15 @@ def workspace(nbytes, slot=0):
     so one buffer per stream (and slot) is shared by every op.  Slot 1 carries the instance-norm partials
     from a convolution epilogue to the norm that follows it.  Inside a hipGraph capture the buffers belong to the graph
     (capture_workspaces)."""
-    _ws_scope = getattr(_ws_tls, 'scope', None)
-    if _ws_scope is not None:
+    scope = _ws_scope[0]
+    if scope is not None:
         key = (_stream_handle(), slot)
-        buf = _ws_scope.get(key)
+        buf = scope.get(key)
         if buf is None or buf.numel() < nbytes:
             n = (max(int(nbytes), 1 << 20) + (1 << 20) - 1) & ~((1 << 20) - 1)
             if buf is not None:
-                _ws_scope.setdefault('retired', []).append(buf)      # kernels captured so far keep writing to it
-            buf = _ws_scope[key] = torch.empty(n, dtype=torch.uint8, device="cuda")
+                scope.setdefault('retired', []).append(buf)      # kernels captured so far keep writing to it
+            buf = scope[key] = torch.empty(n, dtype=torch.uint8, device="cuda")
         return buf
     dev = (_stream_handle(), slot)   # one scratch per stream (stream handles are unique across devices)
     if torch.cuda.is_current_stream_capturing():

@@ -28,6 +28,7 @@ p=[json.loads(l) for l in open(sys.argv[1]) if l.startswith('{')][-1]; e=p['exac
 print(sys.argv[1].split('/')[-1], 'split', p['ms_per_step'], 'exact_fp32', e['ms_per_step'], e['step_frac'], e.get('kernel'), e.get('kernel_avg_us'), e.get('all_conv_kernels_tflops'))
 PY
 done ;;
+    stat0)   CG_FP32_CHUNKED_SUM=0 run stat0 600 python -m pytest tests/test_gpu_parity_full.py -q -s -p no:cacheprovider -k generator_gradient_statistic; grep -A16 "generator-gradient l2-rel\|quiet level" $O/stat0.log | cut -c1-200; tail -3 $O/stat0.log ;;
     stat32)  run stat32 600 python -m pytest tests/test_gpu_parity_full.py -x -q -s -p no:cacheprovider -k "statistic_exact_fp32"; grep -A20 "generator-gradient l2-rel" $O/stat32.log | cut -c1-110; tail -3 $O/stat32.log ;;
     abgroup) bash tools/ab_step.sh ${O#gpurun_out/}/abgroup "new" "nogroup:CG_WGRAD_XCD_GROUP=0" 2>&1 | tee $O/abgroup.log ;;
     abbound) bash tools/ab_step.sh ${O#gpurun_out/}/abbound "new" "bounded:CG_BOUNDED_SPLIT=1" "fused:CG_BOUNDED_SPLIT=1 CG_FUSED_ACT_BWD=1" 2>&1 | tee $O/abbound.log ;;
@@ -39,12 +40,12 @@ done ;;
     pmc3)    pmc wg_128x128 conv_wgrad_x3t 1 "" "tools/ab_wgrad.py --launch 2 8" ;;
     pmc4)    pmc wg_64x128 conv_wgrad_x3t 1 "" "tools/ab_wgrad.py --launch 1 8" ;;
     pmc5)    pmc wg_wide conv_wgrad_x3tw 1 "" "tools/ab_wgrad.py --launch 0 8" ;;
-    pmc16)   AB_ACT=0 pmc x3w conv_fwd_x3w 16 "" ;;
+    pmc16)   AB_ACT=0 pmc x3w conv_fwd_x3w 16 ""; python tools/pmc_record.py $O/pmc_x3w/summary.txt > $O/pmc_record.json 2>&1; cp profiles/pmc_traffic.json $O/pmc_traffic.json ;;
     bench)   run bench 400 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-exact-fp32 --no-other-configs --shape-report $O/conv_shapes.txt; grep -o '"value": [0-9.]*, "unit": "images/sec", "n_gpus": [0-9]*, "steps": [0-9]*, "warmup": [0-9]*, "ms_per_step": [0-9.]*' $O/bench.log ;;
     bench_full) run bench_full 900 python bench.py --shape-report $O/conv_shapes_full.txt; tail -c 3000 $O/bench_full.log ;;
     prof)    STEPS=5 BENCH_ARGS="--no-kernel-profile --no-exact-fp32 --no-other-configs" timeout -k 5 400 bash tools/prof_bench.sh ${O#gpurun_out/}/prof < /dev/null > $O/prof.log 2>&1; echo "== prof t=$(el)"; head -50 $O/prof/alone.txt | cut -c1-140 ;;
     tests_all) run tests_all 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider --durations=15; tail -25 $O/tests_all.log ;;
-    stat)    run stat 600 python -m pytest tests/test_gpu_parity_full.py -x -q -s -p no:cacheprovider -k generator_gradient_statistic; tail -30 $O/stat.log | cut -c1-200 ;;
+    stat)    run stat 600 python -m pytest tests/test_gpu_parity_full.py -q -s -p no:cacheprovider -k generator_gradient_statistic; grep -A16 "generator-gradient l2-rel\|quiet level" $O/stat.log | cut -c1-200; tail -3 $O/stat.log ;;
     one_member) run one_member 400 python tools/one_member_rank.py; tail -20 $O/one_member.log | cut -c1-200 ;;
     py:*)    a=${st#py:}; run py_$(echo $a | tr -c 'A-Za-z0-9' '_' | cut -c1-40) 400 python ${a//,/ } ;;
     *) echo "unknown stage $st" ;;
