@@ -230,6 +230,9 @@ def cpu_baseline(cfg, tr_state_fn, size, batch_full, timed=2):
     dt = min(samples)
     return {"value": round(batch_full / dt, 5), "unit": "images/sec", "cores": threads, "host_cores": cores, "kind": "port",
             "batch": batch_full, "seconds_per_iteration": [round(v, 2) for v in samples],
+            "calibration": "the oracle skips the reference's redundant passes (W_ref 20.78 vs W_min 14.68 TFLOP per iteration): on the build "
+                           "container's 8 vCPUs the SAME iteration takes 57.3 s on the oracle and 95.3 s on the unmodified reference "
+                           "(tools/cpu_calibrate.py, profiles/r06_f_cpu_calibration.txt) -- the reference itself is ~0.60 x this value",
             "sample": "oracle/council_oracle.py on the GPU line's own configuration: %dx%d council=%d batch=%d, one whole iteration "
                       "(dis + dis_council + gen updates of all members) per sample; 1 batch-1 warm-up iteration (%.1f s) + %d timed "
                       "iterations (%s s), fastest reported; %d torch threads = min(%d host cores, 32)"
