@@ -499,6 +499,14 @@ def main():
 
     _STAGE[0] = "warm-up / timed steps (first image exchange over %s; graph capture: %s)" % (
         backend if world > 1 else "no collective", "on" if trainer._graph_mode else "off")
+    if getattr(trainer, '_auto', None) is not None:
+        # sharded ranks choose eager / graph replay by measurement during their first four iterations (cg_graph 'auto',
+        # trainer.cuda()): setup work like the captures below -- run it before the W warm-up steps
+        it0 = -16
+        while trainer._auto is not None and it0 < -8:
+            step(it0)
+            it0 += 1
+        graph_requested = bool(trainer._graph_mode)
     if trainer._graph_mode:
         # hipGraph mode: one eager pass and the captures are setup work (like building the model), not warm-up steps of a
         # replaying job -- run them before the W warm-up steps so that W = 0 or 1 still times replays only
@@ -538,6 +546,7 @@ def main():
                                   "note": "HIP events around the one all-gather of an iteration, mean over the timed steps"}
                                  if min(exch) >= 0 else None),
                  "graph_mode": bool(trainer._graph_mode), "graph_requested": graph_requested,
+                 "graph_auto": getattr(trainer, 'graph_auto', None),
                  "graph_fallback": bool(graph_requested and not trainer._graph_mode),
                  "native_collectives": trainer.shard.slice_comm is not None, "native_fallback": native_fallback[0]}
     ms_per_step = 1000.0 * elapsed / args.steps

@@ -2543,6 +2543,8 @@ static int conv2d_wgrad_x3_impl(const cg_conv_geom* g, const cg_group* group, co
 #define WGX(BM_, BN_, WM_, WN_) \
     rc = launch_wgrad_x3<BM_, BN_, WM_, WN_>(g, p, xs, x_lo_elems, x_scale_dev, dzs, dz_lo_elems, dz_scale_dev, part, M, K, want_bias, st, gr.n)
 #endif
+    // (64x64 wave tiles on the 128x128 / 256x128 tiles -- 4 / 8 waves, 0.67 transposing reads per MFMA instead of 1.0 -- measured in round 6:
+    // -6 ... -15 % at half the occupancy, gpurun_out/s12; not kept)
     if (p.bm == 128 && p.bn == 128) WGX(128, 128, 64, 32);   // 8 waves
 #if CG_X3_INTERLEAVE
     else if (p.bm == 256 && p.bn == 256)                     // experimental wide tile (CG_WGRAD_X3_WIDE)

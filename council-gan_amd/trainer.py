@@ -33,6 +33,7 @@ import contextlib
 import gc
 import os
 import random
+import time
 import warnings
 
 import numpy as np
@@ -284,8 +285,21 @@ class Council_Trainer(nn.Module):
         # the two discriminator-side updates: 68.5 vs 69.1 ms per step, profiles/r03_g_*).
         # ... and on for a single gen / dis pair (council 1: a short, enqueue-bound step with no second update to overlap:
         # 8.89 eager vs 8.44 ms replayed at 128x128 batch 8, profiles/r03_s_graph_vs_eager.txt)
-        dflt = '1' if ((self.shard.world_size > 1 and self.shard.dp == 1) or self.council_size == 1) else '0'
-        self._graph_mode = str(self._hp_cfg.get('cg_graph', os.environ.get('CG_GRAPH', dflt))) == '1' and self.shard.dp == 1
+        # Round 6: a SHARDED rank decides by measurement ('auto').  Graph replay runs the two discriminator-side updates on one stream
+        # where eager overlaps them on two: on a one-member rank eager is 19.05 ms against 19.76 ms replayed (profiles/
+        # r06_one_member_rank.txt) -- provided the host keeps up (14.2 ms of enqueue work per iteration on the pool's boxes).  'auto'
+        # starts eagerly, times iterations 3 and 4 (host's own enqueue work against the iteration's GPU time, queue empty at the
+        # start) and switches to graph replay for the rest of the run when the host needs more than CG_GRAPH_AUTO_RATIO (0.80) of
+        # the GPU time (same call, a one-member rank: host 14.7 of 18.75 ms -> eager 18.75 vs 19.16 ms replayed; host 18.0 ms -> eager 19.24: the
+        # eager gain needs head-room).  Eager and replayed iterations are bit-identical and issue the same collectives in the same order, so
+        # ranks may decide differently.
+        dflt = 'auto' if (self.shard.world_size > 1 and self.shard.dp == 1) else ('1' if self.council_size == 1 else '0')
+        mode = str(self._hp_cfg.get('cg_graph', os.environ.get('CG_GRAPH', dflt)))
+        self._graph_mode = mode == '1' and self.shard.dp == 1
+        self._auto = None
+        self.graph_auto = None                  # the decision of an 'auto' run, for logs / the bench line
+        if mode == 'auto' and self.shard.dp == 1:
+            self._auto = {'it': 0, 'host': [], 'gpu': [], 'ratio': float(os.environ.get('CG_GRAPH_AUTO_RATIO', '0.80'))}
         self._graph_warmup = max(1, int(os.environ.get('CG_GRAPH_WARMUP', '1')))
         # captured graphs kept resident per segment kind (LRU).  Each keeps its private activation pool: 2 (the default) doubles
         # the pools of a kind whose schedule flags alternate (council.flipOnOff) -- README "hipGraph mode"; parsed ONCE, here
@@ -625,6 +639,39 @@ class Council_Trainer(nn.Module):
         for k, v in out.items():
             setattr(self, k, v)
 
+    def _auto_begin(self):
+        """cg_graph 'auto' (sharded ranks): iterations 3 and 4 start from an empty queue and are timed (see cuda())."""
+        a = self._auto
+        if a is None:
+            return
+        a['it'] += 1
+        a.pop('t0', None)
+        if a['it'] in (3, 4):
+            torch.cuda.synchronize(self._device)
+            a['t0'] = time.perf_counter()
+
+    def _auto_end(self):
+        a = self._auto
+        if a is None or 't0' not in a:
+            return
+        t1 = time.perf_counter()
+        torch.cuda.synchronize(self._device)
+        t2 = time.perf_counter()
+        a['host'].append(t1 - a['t0'])
+        a['gpu'].append(t2 - a['t0'])
+        del a['t0']
+        if len(a['host']) >= 2:
+            host, gpu = min(a['host']), min(a['gpu'])
+            use_graph = host > a['ratio'] * gpu
+            self.graph_auto = {'host_ms': round(1e3 * host, 2), 'gpu_ms': round(1e3 * gpu, 2), 'threshold': a['ratio'],
+                               'graph': bool(use_graph)}
+            self._auto = None
+            if use_graph:                      # from the next iteration on: warm-up, capture, replay -- on the caller's stream
+                self._graph_mode = True
+                self._overlap = False
+                self._side = []
+                self._e0 = None
+
     def _leave_graph_mode(self, key, err):
         """A segment could not be captured (a driver / collective-library interaction this build has not met): drop every
         reference to tensors of the abandoned capture and continue eagerly for the rest of the run."""
@@ -779,6 +826,7 @@ class Council_Trainer(nn.Module):
         x = {'a2b': self._img(x_a, 'a'), 'b2a': self._img(x_b, 'b')}      # source image per direction
         tgt = {'a2b': x['b2a'], 'b2a': x['a2b']}                 # real image of the target domain
         groups = self._plan_groups(x[self._dirs[0]])
+        self._auto_begin()
         if self._graph_mode:
             self._rep_cache.clear()            # the static input buffers hold a new batch: repeat it again (inside the body)
             self._iter_eager, self._phase = False, 1       # a new iteration starts here (train.py:244-250 call order)
@@ -1031,6 +1079,7 @@ class Council_Trainer(nn.Module):
         key = ('gen', tuple(x[self._dirs[0]].shape), tuple(map(tuple, groups)), tuple(sorted(flags.items())), self._opt_key('gen'))
         with self._fresh_mirrors('gen', 'dis', 'disc'):
             self._run(key, lambda: self._gen_body(x, groups, flags, s_dev, pos_dev, hyper))
+        self._auto_end()
 
     def _gen_body(self, x, groups, f, s_dev, pos_dev, hyper):
         lib = hip.load()

@@ -252,7 +252,7 @@ def test_single_rank_communicator_of_the_c_abi():
 def test_bench_launches_its_ranks_on_the_gpu_box(tmp_path):
     """`python bench.py --gpus 2` with no launcher around it (the driver's command): two ranks start, rendezvous on 127.0.0.1,
     shard council 4 two members each, run real training steps (both share this box's one GPU; gloo carries the exchange) in
-    hipGraph mode -- the default of a sharded run -- and rank 0 prints ONE JSON line with n_gpus = 2."""
+    the default mode of a sharded run (eager or graph replay, decided by measurement) -- and rank 0 prints ONE JSON line with n_gpus = 2."""
     import json
     import subprocess
     import sys
@@ -267,4 +267,7 @@ def test_bench_launches_its_ranks_on_the_gpu_box(tmp_path):
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0
-    assert out["config"]["members_per_gpu"] == 2 and "hipGraph replay of the updates (CG_GRAPH): on" in out["config"]["execution"]
+    assert out["config"]["members_per_gpu"] == 2 and "hipGraph replay of the updates (CG_GRAPH): " in out["config"]["execution"]
+    # a sharded run decides eager / graph replay by measurement (cg_graph 'auto'): the decision and what it was taken on are in the line
+    ga = out["graph_auto"]
+    assert ga is not None and ga["gpu_ms"] > 0 and ga["host_ms"] > 0 and out["graph_mode"] == ga["graph"], out.get("graph_auto")

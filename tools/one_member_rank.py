@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--graph", default="both", choices=["0", "1", "both"])
+    ap.add_argument("--graph", default="both", choices=["0", "1", "auto", "both"], help="both = eager, graph replay, then the sharded default 'auto'")
     ap.add_argument("--kernels", action="store_true", help="per-kernel totals of one iteration (torch profiler)")
     ap.add_argument("--shapes", default="", help="write the per-layer-shape conv timing table of one eager iteration here")
     args = ap.parse_args()
@@ -44,7 +44,7 @@ def main():
     x_a, x_b = cga.synthetic_batch(args.batch, args.size)
     x_a, x_b = x_a.cuda(), x_b.cuda()
 
-    for graph in (["0", "1"] if args.graph == "both" else [args.graph]):
+    for graph in (["0", "1", "auto"] if args.graph == "both" else [args.graph]):
         c = dict(cfg, cg_graph=graph)
         cga.seed_everything(cfg['random_seed'])
         shard = CouncilShard(args.council, rank=0, world_size=args.world)
@@ -53,7 +53,7 @@ def main():
         shard.exchange_flat = lambda local: local.repeat(ranks, 1, 1, 1).contiguous(memory_format=torch.channels_last)
         tr = cga.Council_Trainer(c, 'cuda:0', shard=shard)
         tr.cuda('cuda:0')
-        assert tr._graph_mode == (graph == "1") and len(shard.local) == per
+        assert (graph == "auto" or tr._graph_mode == (graph == "1")) and len(shard.local) == per
 
         def step(it):
             c['iteration'] = 60000 + it
@@ -61,9 +61,12 @@ def main():
             tr.dis_council_update(x_a, x_b, c)
             tr.gen_update(x_a, x_b, c, c['iteration'])
 
-        for it in range(4):
+        for it in range(8 if graph == "auto" else 4):      # 'auto' decides on its iterations 3 and 4, then (maybe) captures
             step(it)
         torch.cuda.synchronize()
+        if graph == "auto":
+            print("cg_graph auto decided:", tr.graph_auto, flush=True)
+            graph = "auto->%s" % ("graph" if tr._graph_mode else "eager")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()
