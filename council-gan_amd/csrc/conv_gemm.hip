@@ -1806,6 +1806,213 @@ int launch_fwd_thin(const cg_conv_geom* g, const float* x1, const float* x2, con
     return CG_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// conv_fwd_thin_x3_kernel (round 6): the THIN-input layers (3 / 6 / 12 -> 64 channels) of the split-precision datapath on the fp16 MFMA.
+// Same spatial blocking, persistent tile walk, LDS patch and 16-byte stores as conv_fwd_thin_kernel, but the K = taps x channels
+// products are evaluated as  wh*ph + wh*pl + wl*ph  on v_mfma_f32_32x32x16_f16 (K padded to a multiple of 16 with zero weights):
+// 12 MFMAs of 32 cycles per 32x32 output tile for the 3x3x6 layer instead of 27 fp32 MFMAs of 64 -- the fp32 kernel spends half
+// its time in the matrix pipe, this one is bound by its 256 output bytes per pixel.
+//   * the patch is stored in LDS as ONE dword per element, {hi half | lo half << 16} of the fp32 value (converted once, when the
+//     tile is staged): a lane gathers the 8 k's of its fragment with 8 ds_read_b32 at offsets it reads from a small LDS table
+//     (k -> patch offset, computed once per block) and separates the planes with two v_perm per dword pair;
+//   * this lane's rows of the weight matrix, both planes, stay in registers for the block's whole tile list (K16 / 2 VGPRs),
+//     pre-multiplied by CG_X3_WSCALE like every split weight.
+// Operands as in conv_fwd_thin_kernel after round 6's swap: A = weights (D rows = output channels), B = patch (D columns = pixels).
+// ------------------------------------------------------------------------------------------
+// (144-184 registers: one block per CU; held to 128 registers for a second block the 3x3x6 / 4x4x3 variants spill and lose more than
+// the second block gains -- 453 vs 333 us on the council discriminator's first layer, gpurun_out/s15)
+template <int KH, int KW, int CT, int S>
+__global__ __launch_bounds__(512) void conv_fwd_thin_x3_kernel(
+    cg_conv_geom g, const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ w,
+    const float* __restrict__ bias, float* __restrict__ y, int imgs_per_member, int pad_y, int pad_x,
+    float* __restrict__ amax_state, Members mb) {
+    constexpr int TH = 16, TW = 16, NT = 512, BN = 64;
+    constexpr int K = KH * KW * CT, RL = KW * CT, K16 = (K + 15) / 16 * 16, KSTEPS = K16 / 16;
+    constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, PN = PH * PW * CT;
+    constexpr int PV = (PN + NT - 1) / NT;                      // patch elements per thread
+    __shared__ unsigned patch[2][PN];                           // {hi | lo << 16} per element
+    __shared__ __attribute__((aligned(16))) int koffs[K16];     // k -> offset inside a patch (k >= K: 0, its weight is zero)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w) + (long long)blockIdx.z * mb.w_stride);
+    if (bias) bias = reinterpret_cast<const float*>(reinterpret_cast<const char*>(bias) + (long long)blockIdx.z * mb.b_stride);
+
+    for (int k = tid; k < K16; k += NT) koffs[k] = k < K ? (k / RL) * (PW * CT) + (k % RL) : 0;
+
+    // this lane's row of the weight matrix (output channel wn * 32 + l31), k = 16 ks + 8 lh + e, as {hi, lo} halves of 1024 w
+    cg_f16x8 wh[KSTEPS], wl[KSTEPS];
+    {
+        const float* wrow = w + (size_t)(wn * 32 + l31) * K;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = ks * 16 + lh * 8 + e;
+                const float v = k < K ? wrow[k] * CG_X3_WSCALE : 0.f;
+                _Float16 h, l;
+                split_f16(v, h, l);
+                wh[ks][e] = h;
+                wl[ks][e] = l;
+            }
+        }
+    }
+    // this lane's 16 output channels: wn * 32 + 8 q + 4 lh + {0..3}, q = 0..3 (the D rows of its half-wave)
+    float4 bj4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float* bq = bias + wn * 32 + 8 * q + 4 * lh;
+        bj4[q] = bias ? make_float4(bq[0], bq[1], bq[2], bq[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        cg_touch(bj4[q].x);
+        cg_touch(bj4[q].y);
+        cg_touch(bj4[q].z);
+        cg_touch(bj4[q].w);
+    }
+    // LDS offsets of this lane's two pixel columns: column r of the tile is pixel (r / 16, r % 16)
+    int rb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + i * 32 + l31;
+        rb[i] = (((r >> 4) * S) * PW + (r & 15) * S) * CT;
+    }
+
+    const int tiles_x = (g.Wo + TW - 1) / TW, tiles_y = (g.Ho + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y, ntiles = imgs_per_member * tiles_img;
+    const int img0 = (int)blockIdx.z * imgs_per_member;
+    float vmax = 0.f;
+    float pv[PV];
+    auto fetch_patch = [&](int t) {
+        const int n = img0 + t / tiles_img, tr = t % tiles_img;
+        const int iy0 = (tr / tiles_x) * TH * S - pad_y, ix0 = (tr % tiles_x) * TW * S - pad_x;
+#pragma unroll
+        for (int j = 0; j < PV; ++j) {
+            const int e = tid + j * NT;
+            const int pix = e / CT, c = e - pix * CT;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            float v = 0.f;
+            if (e < PN && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) {
+                const size_t p = ((size_t)n * g.H + iy) * g.W + ix;
+                v = c < g.C1 ? x1[p * g.C1 + c] : x2[p * g.C2 + (c - g.C1)];
+            }
+            pv[j] = v;
+        }
+    };
+    auto store_patch = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < PV; ++j) {
+            const int e = tid + j * NT;
+            if (e < PN) {
+                _Float16 h, l;
+                split_f16(pv[j], h, l);
+                patch[buf][e] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+            }
+        }
+    };
+    int cur = 0;
+    if ((int)blockIdx.x < ntiles) {
+        fetch_patch(blockIdx.x);
+        store_patch(0);
+    }
+    __syncthreads();
+    const float inv_scale = 1.f / CG_X3_WSCALE;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int n = img0 + t / tiles_img, tr = t % tiles_img;
+        const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+        const bool more = t + (int)gridDim.x < ntiles;
+        if (more) fetch_patch(t + gridDim.x);                   // global loads in flight under the MFMAs below
+        const unsigned* __restrict__ pt = patch[cur];
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int4 o0 = *reinterpret_cast<const int4*>(&koffs[ks * 16 + lh * 8]);
+            const int4 o1 = *reinterpret_cast<const int4*>(&koffs[ks * 16 + lh * 8 + 4]);
+            const int off[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                unsigned d[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] = pt[rb[i] + off[e]];
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 ph, pl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ph[q] = __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x05040100u);      // the two hi halves
+                    pl[q] = __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x07060302u);      // the two lo halves
+                }
+                // small terms first, the dominant hi*hi product last (as every split-precision kernel)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], __builtin_bit_cast(cg_f16x8, ph), acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], __builtin_bit_cast(cg_f16x8, pl), acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], __builtin_bit_cast(cg_f16x8, ph), acc[i], 0, 0, 0);
+            }
+        }
+
+        // C/D layout of the 32x32 MFMA: col = lane % 32 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane / 32) (channel)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + l31;
+            const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+            if (oy < g.Ho && ox < g.Wo) {
+                float* __restrict__ dst = y + (((size_t)n * g.Ho + oy) * g.Wo + ox) * BN + wn * 32 + 4 * lh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v;
+                    v.x = cg_apply_act(acc[i][4 * q + 0] * inv_scale + bj4[q].x, g.act);
+                    v.y = cg_apply_act(acc[i][4 * q + 1] * inv_scale + bj4[q].y, g.act);
+                    v.z = cg_apply_act(acc[i][4 * q + 2] * inv_scale + bj4[q].z, g.act);
+                    v.w = cg_apply_act(acc[i][4 * q + 3] * inv_scale + bj4[q].w, g.act);
+                    *reinterpret_cast<float4*>(dst + 8 * q) = v;
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
+            }
+        }
+        if (more) store_patch(cur ^ 1);                         // last read by the previous tile, released by its barrier
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (amax_state) block_amax_store<NT>(vmax, amax_state);
+}
+
+template <int KH, int KW, int CT, int S>
+int launch_fwd_thin_x3(const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias, float* y, int M,
+                       hipStream_t st, const Grp& gr) {
+    const int imgs = M / (g->Ho * g->Wo);                       // images of ONE member
+    const int ntiles = imgs * ((g->Ho + 15) / 16) * ((g->Wo + 15) / 16);
+    int gx = 512 / gr.n;                                        // two resident blocks per CU over all members
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    dim3 grid(gx, 1, gr.n), block(512);
+    float* amax = nullptr;
+    if (fwd_amax.state) {
+        fwd_amax.nslots = amax_slots_for((long)gx * gr.n, fwd_amax.state, st);
+        if (fwd_amax.nslots) amax = fwd_amax.state;
+    }
+    ProfScope prof(8, 256, 64, true, 2.0 * (double)M * gr.n * 64.0 * (double)(KH * KW * CT), st, g, gr.n);
+    hipLaunchKernelGGL((conv_fwd_thin_x3_kernel<KH, KW, CT, S>), grid, block, 0, st, *g, x1, x2, w, bias, y, imgs, -(int)g->dy[0],
+                       -(int)g->dx[0], amax, members_f32(gr));
+    CG_LAUNCH_CHECK("conv_fwd_thin_x3_kernel");
+    return CG_OK;
+}
+
+int launch_fwd_thin_x3_variant(int v, const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
+                               float* y, int M, hipStream_t st, const Grp& gr) {
+    switch (v) {
+        case 0: return launch_fwd_thin_x3<7, 7, 3, 1>(g, x1, x2, w, bias, y, M, st, gr);
+        case 1: return launch_fwd_thin_x3<4, 4, 3, 2>(g, x1, x2, w, bias, y, M, st, gr);
+        case 2: return launch_fwd_thin_x3<3, 3, 6, 1>(g, x1, x2, w, bias, y, M, st, gr);
+        case 3: return launch_fwd_thin_x3<3, 3, 3, 1>(g, x1, x2, w, bias, y, M, st, gr);
+        case 4: return launch_fwd_thin_x3<1, 1, 12, 1>(g, x1, x2, w, bias, y, M, st, gr);
+        default: return cg_set_error(CG_ERR_ARG, "thin conv (split precision): no such variant");
+    }
+}
+
 int launch_fwd_thin_variant(int v, const cg_conv_geom* g, const float* x1, const float* x2, const float* w, const float* bias,
                             float* y, int M, hipStream_t st, const Grp& gr) {
     switch (v) {
@@ -1889,6 +2096,11 @@ int launch_fwd_cfg(int cfg, const cg_conv_geom* g, const float* x1, const float*
             const int v = thin_match(g);
             if (v < 0) return cg_set_error(CG_ERR_ARG, "conv forward: configuration 40 needs a thin-input layer (3/6/12 -> 64 channels)");
             return launch_fwd_thin_variant(v, g, x1, x2, w, bias, y, M, st, gr);
+        }
+        case 41: {     // the same layers on the fp16 x 3 MFMA (cg_conv2d_fwd_thin_x3_g)
+            const int v = thin_match(g);
+            if (v < 0) return cg_set_error(CG_ERR_ARG, "conv forward: configuration 41 needs a thin-input layer (3/6/12 -> 64 channels)");
+            return launch_fwd_thin_x3_variant(v, g, x1, x2, w, bias, y, M, st, gr);
         }
         default: return cg_set_error(CG_ERR_ARG, "conv forward: unknown tile configuration %d", cfg);
     }
@@ -2127,6 +2339,26 @@ extern "C" int cg_conv2d_fwd_g(const cg_conv_geom* g, const cg_group* group, con
     fwd_amax.nslots = 0;
     const int rc = conv2d_fwd_impl(g, group, x1, x2, w, bias, y, -1, stats, stats_bytes, rows_per_partial, stream,
                                    "cg_conv2d_fwd_g");
+    if (amax_nslots) *amax_nslots = rc ? 0 : fwd_amax.nslots;
+    fwd_amax.state = nullptr;
+    return rc;
+}
+
+// thin-input layers (3 / 6 / 12 -> 64 channels) of the split-precision datapath: fp32 tensors in and out like cg_conv2d_fwd_g, the
+// products on the fp16 x 3 MFMA (conv_fwd_thin_x3_kernel)
+// (not the 12 -> 64 1x1 layer: one k-step of work per tile, the fp32 kernel is faster there -- 77 vs 83 us, gpurun_out/s14)
+extern "C" int cg_conv2d_fwd_thin_x3_ok(const cg_conv_geom* g) {
+    if (!g || !CG_X3_INTERLEAVE) return 0;
+    const int v = thin_match(g);
+    return v >= 0 && v != 4;
+}
+extern "C" int cg_conv2d_fwd_thin_x3_g(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2, const float* w,
+                                       const float* bias, float* y, float* amax_state, int* amax_nslots, cg_stream_t stream) {
+    CG_CHECK_ARG((amax_state == nullptr) == (amax_nslots == nullptr), "cg_conv2d_fwd_thin_x3_g: amax_state and amax_nslots go together");
+    CG_CHECK_ARG(cg_conv2d_fwd_thin_x3_ok(g), "cg_conv2d_fwd_thin_x3_g: not a thin-input layer (see cg_conv2d_fwd_thin_x3_ok)");
+    fwd_amax.state = amax_state;
+    fwd_amax.nslots = 0;
+    const int rc = conv2d_fwd_impl(g, group, x1, x2, w, bias, y, 41, nullptr, 0, nullptr, stream, "cg_conv2d_fwd_thin_x3_g");
     if (amax_nslots) *amax_nslots = rc ? 0 : fwd_amax.nslots;
     fwd_amax.state = nullptr;
     return rc;

@@ -65,6 +65,8 @@ _SIGS = {
                                    c_size_t, _P, c_size_t, POINTER(c_int), c_int, _P, POINTER(c_int), _P]),
     "cg_conv2d_fwd_g": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, _P, _P, _P, _P, _P, c_size_t, POINTER(c_int), _P,
                                 POINTER(c_int), _P]),
+    "cg_conv2d_fwd_thin_x3_ok": (c_int, [POINTER(ConvGeom)]),
+    "cg_conv2d_fwd_thin_x3_g": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, _P, _P, _P, _P, _P, POINTER(c_int), _P]),
     "cg_split_f16_dynamic_capped": (c_int, [_P, _P, c_size_t, c_size_t, _P, c_int, c_float, _P]),
     "cg_conv2d_dgrad_x3_wt_elems": (c_size_t, [POINTER(ConvGeom), c_int]),
     "cg_conv2d_dgrad_x3_prep": (c_int, [POINTER(ConvGeom), POINTER(Group), _P, c_int, c_int, c_float, _P, _P, c_size_t, _P]),

@@ -229,8 +229,14 @@ class _Conv2d(torch.autograd.Function):
         else:
             if amax_out is not None and not want_stats:
                 state, nslots = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=y.device), ctypes.c_int(0)
-            check(lib.cg_conv2d_fwd_g(byref(g), grp, ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), ptr(sws), sbytes, rp,
-                                      ptr(state), byref(nslots) if nslots is not None else None, stream()), "cg_conv2d_fwd")
+            if X3_FORWARD and THIN_X3 and lib.cg_conv2d_fwd_thin_x3_ok(byref(g)):
+                # thin-input first layers (3 / 6 / 12 -> 64 channels) of the split-precision datapath: fp32 tensors in and out, the
+                # products on the fp16 x 3 MFMA (round 6; no epilogue statistics on this kernel: rows stays 0, the norm measures itself)
+                check(lib.cg_conv2d_fwd_thin_x3_g(byref(g), grp, ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), ptr(state),
+                                                  byref(nslots) if nslots is not None else None, stream()), "cg_conv2d_fwd_thin_x3")
+            else:
+                check(lib.cg_conv2d_fwd_g(byref(g), grp, ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(y), ptr(sws), sbytes, rp,
+                                          ptr(state), byref(nslots) if nslots is not None else None, stream()), "cg_conv2d_fwd")
         if nslots is not None and nslots.value:
             amax_out.append((state, nslots.value))
         if want_stats and rows.value:
@@ -436,6 +442,8 @@ def wgrad_join():
 UPC_WSCALE = 0.25      # the summed-tap weights are up to 4x a weight: a quarter of the pool's scale keeps their hi halves finite
 # CG_UPCONV=0: the upsampling layers run as 3x3 convolutions that gather through the upsample (A/B switch)
 UPCONV = os.environ.get("CG_UPCONV", "1") != "0"
+# CG_THIN_X3=0: the thin-input first layers stay on the exact-fp32 MFMA kernel under the split-precision datapath too (A/B switch)
+THIN_X3 = os.environ.get("CG_THIN_X3", "1") != "0"
 _upc_groups = {}
 
 

@@ -127,6 +127,13 @@ int cg_conv2d_fwd_x3_g(const cg_conv_geom* g, const cg_group* group, const void*
 int cg_conv2d_fwd_g(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2, const float* w,
                     const float* bias, float* y, double* stats, size_t stats_bytes, int* rows_per_partial,
                     float* amax_state, int* amax_nslots, cg_stream_t stream);
+/* The thin-input first layers (3 / 6 / 12 -> 64 channels: the generators' 7x7, the discriminators' 4x4 stride-2 and two-source 3x3,
+ * the decoder's 12 -> 64 1x1; networks.py:44,152,385-386) under the split-precision datapath: fp32 tensors in and out exactly like
+ * cg_conv2d_fwd_g (no instance-norm partials), the products evaluated as wh*xh + wh*xl + wl*xh on the fp16 MFMA from {hi, lo}
+ * halves built inside the kernel.  cg_conv2d_fwd_thin_x3_ok(g) != 0 iff the geometry is one of those layers. */
+int cg_conv2d_fwd_thin_x3_ok(const cg_conv_geom* g);
+int cg_conv2d_fwd_thin_x3_g(const cg_conv_geom* g, const cg_group* group, const float* x1, const float* x2, const float* w,
+                            const float* bias, float* y, float* amax_state, int* amax_nslots, cg_stream_t stream);
 /* amax_state / amax_nslots (both or neither): the epilogue leaves max|y| per block in amax_state[2 .. 2 + *amax_nslots)
  * (a CG_SPLIT_STATE_FLOATS buffer) for cg_split_f16_dynamic(y, ..., state, nslots), which then skips its own reduction
  * pass over y (launches with more than 1024 blocks share 1024 slots through an atomic max); *amax_nslots = 0 when the

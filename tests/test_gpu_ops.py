@@ -495,6 +495,11 @@ def test_thin_input_convolution(cga, case):
     thin, generic = forced(40), forced(1)
     assert rel(thin, ref) < 3e-6, rel(thin, ref)
     assert rel(thin, generic) < 2e-6
+    # the same layer on the fp16 x 3 MFMA (conv_fwd_thin_x3_kernel, configuration 41): what the split-precision datapath runs
+    takes_x3 = bool(lib.cg_conv2d_fwd_thin_x3_ok(byref(geom)))
+    assert takes_x3 == (K * K * Ct != 12)          # every thin layer but the 12 -> 64 1x1 (faster on the fp32 kernel)
+    thin_x3 = forced(41)
+    assert rel(thin_x3, ref) < 2e-5, rel(thin_x3, ref)
 
     prev = lib.cg_conv2d_fwd_thin(1)
     try:
@@ -503,11 +508,23 @@ def test_thin_input_convolution(cga, case):
             ops.X3_FORWARD = ops.X3_DYNAMIC_INPUT = True       # the split-precision consumers ask producers for block maxima
             try:
                 y = ops.conv2d(x1d, wd, bd, stride, pad, act, x2=x2d)
+                thin_flag, ops.THIN_X3 = ops.THIN_X3, False       # CG_THIN_X3=0: the exact-fp32 kernel under the split datapath too
+                try:
+                    y32path = ops.conv2d(x1d, wd, bd, stride, pad, act, x2=x2d)
+                finally:
+                    ops.THIN_X3 = thin_flag
             finally:
                 ops.X3_FORWARD, ops.X3_DYNAMIC_INPUT = flags
-            assert torch.equal(y, thin)
-            state, nslots = y._cg_amax
-            assert float(state[2:2 + nslots].max()) == float(y.abs().max())
+            assert torch.equal(y, thin_x3 if takes_x3 else thin) and torch.equal(y32path, thin)
+            for out in (y, y32path):
+                state, nslots = out._cg_amax
+                assert float(state[2:2 + nslots].max()) == float(out.abs().max())
+            ops.X3_FORWARD = False                                  # the exact-fp32 datapath keeps the fp32 kernel
+            try:
+                yx = ops.conv2d(x1d, wd, bd, stride, pad, act, x2=x2d)
+            finally:
+                ops.X3_FORWARD = flags[0]
+            assert torch.equal(yx, thin)
             # a layer no variant covers (32 output channels) keeps the generic kernel
             w32 = cl(dev(w[:32]))
             y32 = ops.conv2d(x1d, w32, bd[:32], stride, pad, act, x2=x2d)
@@ -527,6 +544,11 @@ def test_thin_input_convolution(cga, case):
             hip.check(lib.cg_conv2d_fwd_g(byref(geom), byref(grp), hip.ptr(x1d), hip.ptr(x2d), hip.ptr(pool[:nw]),
                                           hip.ptr(pool[nw:nw + 64]), hip.ptr(yg), None, 0, None, None, None, hip.stream()),
                       "cg_conv2d_fwd_g")
+            ygx = torch.full_like(thin, float("nan"))
+            if takes_x3:
+              hip.check(lib.cg_conv2d_fwd_thin_x3_g(byref(geom), byref(grp), hip.ptr(x1d), hip.ptr(x2d), hip.ptr(pool[:nw]),
+                                                    hip.ptr(pool[nw:nw + 64]), hip.ptr(ygx), None, None, hip.stream()),
+                        "cg_conv2d_fwd_thin_x3_g")
             h = N // 2
             gh = ops.fwd_geom(h, H, W, C1, C2, 0, K, K, stride, pad, 64, ops.ACT[act])
             for m, (wm_, bm_) in enumerate(((w, b), (w2, b2))):
@@ -537,6 +559,10 @@ def test_thin_input_convolution(cga, case):
                 hip.check(lib.cg_conv2d_fwd_tile(byref(gh), hip.ptr(xa), hip.ptr(xb), hip.ptr(wmd), hip.ptr(bmd),
                                                  hip.ptr(ym), 40, hip.stream()), "cg_conv2d_fwd_tile")
                 assert torch.equal(yg[m * h:(m + 1) * h], ym)
+                ymx = torch.full_like(ym, float("nan"))
+                hip.check(lib.cg_conv2d_fwd_tile(byref(gh), hip.ptr(xa), hip.ptr(xb), hip.ptr(wmd), hip.ptr(bmd),
+                                                 hip.ptr(ymx), 41, hip.stream()), "cg_conv2d_fwd_tile")
+                assert not takes_x3 or torch.equal(ygx[m * h:(m + 1) * h], ymx)
                 refm = F.conv2d(F.pad(x[m * h:(m + 1) * h], (pad,) * 4), wm_, bm_, stride=stride)
                 refm = {"none": refm, "relu": F.relu(refm), "lrelu": F.leaky_relu(refm, 0.2)}[act]
                 assert rel(ym, refm) < 3e-6

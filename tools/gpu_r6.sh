@@ -34,6 +34,7 @@ done ;;
     abbound) bash tools/ab_step.sh ${O#gpurun_out/}/abbound "new" "bounded:CG_BOUNDED_SPLIT=1" "fused:CG_BOUNDED_SPLIT=1 CG_FUSED_ACT_BWD=1" 2>&1 | tee $O/abbound.log ;;
     ab5)     EXTRA_SHAPES="c128_3x3_128,16,128,128,128,128,3,1,1,0;dg256x4_128_64,16,64,64,256,128,2,1,0,0;c64_128_4x4s2_256,16,256,256,64,128,4,2,1,0;d64_128_4x4s2_128_b32,32,128,128,64,128,4,2,1,0" run ab5 300 python tools/ab_x3.py 13,5,1,0 -; cat $O/ab5.log | cut -c1-200 ;;
 
+    thin)    run thin_test 300 python -m pytest tests/test_gpu_ops.py -q -x -p no:cacheprovider -k "thin"; tail -3 $O/thin_test.log; bash tools/ab_step.sh ${O#gpurun_out/}/abthin "new" "fp32thin:CG_THIN_X3=0" 2>&1 | tee $O/abthin.log; run thin_shapes 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-fp32 --no-other-configs --shape-report $O/thin_shapes.txt; grep "^f8" $O/thin_shapes.txt | cut -c1-130 ;;
     probe4w) run probe4w 200 python tools/probe_x3w_stalls.py 16 53 4; tail -40 $O/probe4w.log | cut -c1-160 ;;
     abwg)    run abwg 300 python tools/ab_wgrad.py; cat $O/abwg.log | cut -c1-200 ;;
     pmc1)    pmc x3_128x64 conv_fwd_x3_kernel 2 "c64,16,256,256,64,64,3,1,1,0" ;;
