@@ -146,6 +146,55 @@ def pmc_traffic(kernel):
     return rec.get("bytes_per_launch"), rec
 
 
+def live_pmc_traffic(kernel, timeout=120):
+    """Memory-side traffic of the dominant kernel's dominant launch MEASURED IN THIS RUN (the committed record is
+    a builder-written file): two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass; kernel trace only, no
+    other trace domain) over tools/ab_x3.py's launch loop of the member-batched res-block launch (3x3 256 -> 256 at 64x64, 16
+    samples, 8 launches, the first two dropped), in child processes of this one.  FETCH_SIZE counts 128-byte requests as 64 bytes
+    on gfx950 (MI355X_MICROARCH.md): x 2.  Returns (bytes per launch, record) or (None, {"error": ...}); only the wide LDS-DMA tile
+    has a launch loop."""
+    import csv
+    import shutil
+    import tempfile
+    if "conv_fwd_x3w_kernel" not in kernel:
+        return None, {"error": "no launch loop for %s" % kernel}
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, {"error": "rocprofv3 not found"}
+    vals, durs = {}, {}
+    tmp = tempfile.mkdtemp(prefix="cg_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp", AB_ACT="0")
+            env.pop("PMC_SHAPE", None)
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                                os.path.join(ROOT, "tools", "ab_x3.py"), "--launch", "16", "16", "8"], cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+            files = glob.glob(os.path.join(out, "*", "*_counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, {"error": "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode()[-300:])}
+            v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                 if "conv_fwd_x3w" in row["Kernel_Name"] and row["Counter_Name"] == counter]
+            kt = glob.glob(os.path.join(out, "*", "*_kernel_trace.csv"))
+            d = [(int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3 for row in csv.DictReader(open(kt[0]))
+                 if "conv_fwd_x3w" in row["Kernel_Name"]] if kt else []
+            if len(v) < 4:
+                return None, {"error": "rocprofv3 --pmc %s: %d launches of the kernel in the trace" % (counter, len(v))}
+            vals[counter] = sum(v[2:]) / len(v[2:])
+            durs[counter] = (sum(d[2:]) / len(d[2:])) if len(d) > 2 else None
+    except Exception as e:      # noqa: BLE001 -- the headline number does not depend on this leg
+        return None, {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    nbytes = int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    return nbytes, {"source": "measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two passes, kernel trace only) over 8 launches of "
+                              "the member-batched res-block launch, tools/ab_x3.py --launch 16 16 8; gfx950 FETCH_SIZE x 2",
+                    "fetch_size_kib": int(vals["FETCH_SIZE"]), "write_size_kib": int(vals["WRITE_SIZE"]), "bytes_per_launch": nbytes,
+                    "algorithmic_bytes_per_launch": 136.6e6, "ratio": round(nbytes / 136.6e6, 2),
+                    "avg_us_under_profiler": round(durs["FETCH_SIZE"], 1) if durs.get("FETCH_SIZE") else None}
+
+
 _STAGE = ["start"]      # where main() currently is (for the error line of guarded_main)
 
 
@@ -406,6 +455,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic in this run")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32-MFMA sub-record")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the cfg2 / cfg5 sub-records the default (cfg3) N = 1 line carries")
@@ -641,6 +691,12 @@ def main():
                 trec = dict(trec, stale="record taken on build %s, this run is build %s: traffic = null"
                                         % (trec.get("build_stamp"), trec.get("build_stamp_now")))
             roof.update({"traffic": tbytes, "traffic_record": trec})
+            if not args.no_live_pmc:
+                # counters measured in THIS run take precedence over the committed record (which stays in the line for comparison)
+                lbytes, lrec = live_pmc_traffic(dname)
+                roof["traffic_live"] = lrec
+                if lbytes is not None:
+                    roof["traffic"] = lbytes
             roof.update({"kernel": dname, "achieved": round(ach, 2), "peak": round(kernel_peak(dname), 1),
                          "frac": round(ach / kernel_peak(dname), 4),
                          "avg_launch_us": round(1000.0 * dms / dc, 2), "launches_per_step": dc,

@@ -715,7 +715,7 @@ __device__ __forceinline__ void dbg_stamp(int tile, int slot) {
 // chunks of FOLD x 16 MFMAs first and the chunk sums afterwards shortens both chains (blocked summation): for FOLD = 4 the expected
 // round-off drops ~3.7x -- below the CPU kernels'.  Costs TM x TN x 16 registers and one v_add per accumulator value and chunk.
 template <int BM, int BN, int WM, int WN, int PF, int ABL, int FOLD = 0>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kernel(
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (FOLD > 0 && BM == 128 && BN == 128 && WM == 64 && WN == 32) ? 4 : 1) void conv_fwd_pipe_kernel(
     PipeBatch batch, const float* __restrict__ x1, const float* __restrict__ bias, float* __restrict__ y,
     unsigned x_bytes, double* __restrict__ stats, Members mb) {
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -799,6 +799,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kern
     float4 av[PF][A_V4], bv[PF][B_V4];
     int ld_kt = 0, ld_tap = 0, ld_c0 = 0;  // slice the next load_tile() fetches (clamped to the last slice)
 
+    // (the chunked-sum 128 x 128 / 8-wave tile re-reads its rows' gather data from the LDS row table instead of holding it in registers:
+    // with one fragment set that brings it to 128 registers -- two blocks per CU)
+    constexpr bool ROWS_LDS = false;      // (measured: 134 registers with it, 130 without)
     auto load_tile = [&](auto set_c) {
         constexpr int SET = decltype(set_c)::value;
         const int td = __builtin_amdgcn_readfirstlane(taps[ld_tap]);
@@ -806,9 +809,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kern
         const unsigned cb = (unsigned)(ld_c0 + kc * 4);
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
-            const int ly = rly[i] + dy, lx = rlx[i] + dx;
-            const bool ok = rbase[i] >= 0 && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
-            const unsigned pix = (unsigned)(rbase[i] + (ly >> g.up) * g.W + (lx >> g.up));
+            int rb_ = rbase[i], ry_ = rly[i], rx_ = rlx[i];
+            if constexpr (ROWS_LDS) {
+                const RowInfo ri = rows[r0 + RPV * i];
+                rb_ = ri.base, ry_ = ri.ly0, rx_ = ri.lx0;
+            }
+            const int ly = ry_ + dy, lx = rx_ + dx;
+            const bool ok = rb_ >= 0 && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
+            const unsigned pix = (unsigned)(rb_ + (ly >> g.up) * g.W + (lx >> g.up));
             // branch-free: an invalid tap only sets the top offset bit, the range check then returns zeros
             av[SET][i] = buf_load4(xr, ((pix * (unsigned)Ct + cb) << 2) | (ok ? 0u : CG_OOB));
         }
@@ -872,7 +880,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kern
 
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    float4 a0[TM], b0[TN], a1[TM], b1[TN];
+    constexpr bool SB = FOLD > 0 && BM == 128 && BN == 128 && WM == 64 && WN == 32;      // single fragment set, see slice()
+    float4 a0[TM], b0[TN], a1[TM], b1[TN];      // (SB: a1 / b1 are never live)
     load_tile(I0());  // slice 0
     store_tile(0, I0());
     if constexpr (PF == 2) {
@@ -897,6 +906,31 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_fwd_pipe_kern
         constexpr int CUR = decltype(cur_c)::value;
         constexpr int STAGE_AT = decltype(stage_at)::value;
         using SET = std::integral_constant<int, PF == 2 ? (CUR ^ 1) : 0>;
+        if constexpr (SB) {
+            // single fragment set (the chunked-sum 128x128 / 8-wave tile: the second accumulator set must not cost the second block
+            // per CU): a k-step's MFMAs issue, then the next k-step's fragments are read into the same registers -- the other three
+            // waves of the SIMD keep the matrix pipe busy meanwhile
+            if constexpr (STAGE_AT == 0) {
+                store_tile(CUR ^ 1, SET());
+                load_tile(SET());
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma(a0, b0);
+            read_frag(CUR, 1, a0, b0);
+            if constexpr (STAGE_AT == 1) {
+                store_tile(CUR ^ 1, SET());
+                load_tile(SET());
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma(a0, b0);
+            read_frag(CUR, 2, a0, b0);
+            mma(a0, b0);
+            read_frag(CUR, 3, a0, b0);
+            mma(a0, b0);
+            __syncthreads();
+            read_frag(CUR ^ 1, 0, a0, b0);
+            return;
+        }
         if constexpr (STAGE_AT == 0) {
             store_tile(CUR ^ 1, SET());
             load_tile(SET());
@@ -1703,9 +1737,9 @@ int launch_pipe_batch(PipeBatch& b, int ncls, const float* x1, const float* bias
     for (int c = ncls; c < 4; ++c) b.c[c].ntiles = 0;
     dim3 grid(max_tiles, ncls, mb.n), block(NT);
     ProfScope prof(2, BM, BN, true, flops, st, &b.c[0].g, ncls * mb.n);
-    // (the chunked-sum variant of the 128 x 128 / 8-wave tile needs 142 registers -- one block per CU instead of two -- and takes the
-    // two-slice prefetch distance to cover for the lost occupancy; held to 128 registers it spills 96 and is slower still)
-    constexpr int PFF = (BM == 128 && BN == 128 && WN == 32 && PF == 1 && ABL == 0) ? 2 : PF;
+    // (the chunked-sum variant of the 128 x 128 / 8-wave tile keeps ONE fragment register set so that its second accumulator set does not
+    // cost the second block per CU -- 142 registers with two; held to 128 by launch bounds it spilled 96, prefetch distance 2 did not help)
+    constexpr int PFF = PF;
     if (ABL == 0 && tune().fp32_chunked_sum)
         hipLaunchKernelGGL((conv_fwd_pipe_kernel<BM, BN, WM, WN, PFF, ABL, ABL == 0 ? 4 : 0>), grid, block, 0, st, b, x1, bias, y, x_bytes, stats, mb);
     else
@@ -2115,9 +2149,8 @@ int pick_fwd_cfg(const cg_conv_geom* g, long M, bool pipe) {
     M *= tune().tile_rows_scale;      // test hook: choose tiles as if the launch had k x the rows (cg_tuning.tile_rows_scale)
     const long blocks128 = ((M + 127) / 128) * ((g->Cout + 127) / 128);
     if (g->Cout > 64) {
-        // chunked sums (cg_tuning.fp32_chunked_sum) cost the 128 x 128 / 8-wave tile its second block per CU (142 registers); the
-        // 256 x 128 tile of 64 x 64 wave tiles runs one block per CU either way, so launches that fill the chip with it take it
-        if (pipe && tune().fp32_chunked_sum && ((M + 255) / 256) * ((g->Cout + 127) / 128) >= 256) return 24;
+        // (chunked sums, cg_tuning.fp32_chunked_sum: the 128 x 128 / 8-wave tile keeps its two blocks per CU with ONE fragment register set,
+        // 128 registers; preferring the 256 x 128 tile for launches that fill the chip measured slower -- 133.6 vs 131.3 ms per step)
         if (blocks128 >= 192) return pipe ? 20 : 6;
         if (pipe) return 23;
         return blocks128 < 96 ? 10 : 3;

@@ -1,7 +1,7 @@
 # same-call A/B of the whole step: $1 = output name, then pairs "label ENV=VALUE" (label new = no env)
 OUT=gpurun_out/$1; shift
 mkdir -p $OUT
-B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-exact-fp32"
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-exact-fp32 --no-live-pmc"
 i=0
 for spec in "$@" "$@"; do
   i=$((i+1)); label=${spec%%:*}; envs=${spec#*:}; [ "$envs" = "$spec" ] && envs=""

@@ -22,7 +22,7 @@ for st in "$@"; do
     abr128)  EXTRA_SHAPES="c128_3x3_128,16,128,128,128,128,3,1,1,0;dg256x4_128_64,16,64,64,256,128,2,1,0,0;c64_128_4x4s2_256,16,256,256,64,128,4,2,1,0;c128_3x3_128_b4,4,128,128,128,128,3,1,1,0;d64_128_4x4s2_128_b32,32,128,128,64,128,4,2,1,0" run abr128 300 python tools/ab_x3.py 13,1,17,64,65,66,68 -; cat $O/abr128.log | cut -c1-260 ;;
     abk128)  EXTRA_SHAPES="c128_3x3_128,16,128,128,128,128,3,1,1,0;dg256x4_128_64,16,64,64,256,128,2,1,0,0;c64_128_4x4s2_256,16,256,256,64,128,4,2,1,0;d64_128_4x4s2_128_b32,32,128,128,64,128,4,2,1,0;dg512x4_256_32,16,32,32,512,256,2,1,0,0" run abk128 300 python tools/ab_x3.py 13,23,1,24 -; cat $O/abk128.log | cut -c1-200 ;;
     abc64)   EXTRA_SHAPES="c64_3x3_256,16,256,256,64,64,3,1,1,0;c64_1x1_256,16,256,256,64,64,1,1,0,0;up128x4_64_128,16,128,128,128,64,2,1,0,0;c64_3x3_256_b4,4,256,256,64,64,3,1,1,0" run abc64 300 python tools/ab_x3.py 2,25,69,70,26,27 -; cat $O/abc64.log | cut -c1-230 ;;
-    exact)   run exact_on 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-other-configs; CG_FP32_CHUNKED_SUM=0 run exact_off 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-other-configs; for f in exact_on exact_off; do python - $O/$f.log <<'PY'
+    exact)   run exact_on 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-other-configs --no-live-pmc; CG_FP32_CHUNKED_SUM=0 run exact_off 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-other-configs --no-live-pmc; for f in exact_on exact_off; do python - $O/$f.log <<'PY'
 import json,sys
 p=[json.loads(l) for l in open(sys.argv[1]) if l.startswith('{')][-1]; e=p['exact_fp32']
 print(sys.argv[1].split('/')[-1], 'split', p['ms_per_step'], 'exact_fp32', e['ms_per_step'], e['step_frac'], e.get('kernel'), e.get('kernel_avg_us'), e.get('all_conv_kernels_tflops'))
@@ -34,7 +34,7 @@ done ;;
     abbound) bash tools/ab_step.sh ${O#gpurun_out/}/abbound "new" "bounded:CG_BOUNDED_SPLIT=1" "fused:CG_BOUNDED_SPLIT=1 CG_FUSED_ACT_BWD=1" 2>&1 | tee $O/abbound.log ;;
     ab5)     EXTRA_SHAPES="c128_3x3_128,16,128,128,128,128,3,1,1,0;dg256x4_128_64,16,64,64,256,128,2,1,0,0;c64_128_4x4s2_256,16,256,256,64,128,4,2,1,0;d64_128_4x4s2_128_b32,32,128,128,64,128,4,2,1,0" run ab5 300 python tools/ab_x3.py 13,5,1,0 -; cat $O/ab5.log | cut -c1-200 ;;
 
-    thin)    run thin_test 300 python -m pytest tests/test_gpu_ops.py -q -x -p no:cacheprovider -k "thin"; tail -3 $O/thin_test.log; bash tools/ab_step.sh ${O#gpurun_out/}/abthin "new" "fp32thin:CG_THIN_X3=0" 2>&1 | tee $O/abthin.log; run thin_shapes 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-fp32 --no-other-configs --shape-report $O/thin_shapes.txt; grep "^f8" $O/thin_shapes.txt | cut -c1-130 ;;
+    thin)    run thin_test 300 python -m pytest tests/test_gpu_ops.py -q -x -p no:cacheprovider -k "thin"; tail -3 $O/thin_test.log; bash tools/ab_step.sh ${O#gpurun_out/}/abthin "new" "fp32thin:CG_THIN_X3=0" 2>&1 | tee $O/abthin.log; run thin_shapes 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-fp32 --no-other-configs --no-live-pmc --shape-report $O/thin_shapes.txt; grep "^f8" $O/thin_shapes.txt | cut -c1-130 ;;
     probe4w) run probe4w 200 python tools/probe_x3w_stalls.py 16 53 4; tail -40 $O/probe4w.log | cut -c1-160 ;;
     abwg)    run abwg 300 python tools/ab_wgrad.py; cat $O/abwg.log | cut -c1-200 ;;
     pmc1)    pmc x3_128x64 conv_fwd_x3_kernel 2 "c64,16,256,256,64,64,3,1,1,0" ;;
@@ -43,7 +43,7 @@ done ;;
     pmc4)    pmc wg_64x128 conv_wgrad_x3t 1 "" "tools/ab_wgrad.py --launch 1 8" ;;
     pmc5)    pmc wg_wide conv_wgrad_x3tw 1 "" "tools/ab_wgrad.py --launch 0 8" ;;
     pmc16)   AB_ACT=0 pmc x3w conv_fwd_x3w 16 ""; python tools/pmc_record.py $O/pmc_x3w/summary.txt > $O/pmc_record.json 2>&1; cp profiles/pmc_traffic.json $O/pmc_traffic.json ;;
-    bench)   run bench 400 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-exact-fp32 --no-other-configs --shape-report $O/conv_shapes.txt; grep -o '"value": [0-9.]*, "unit": "images/sec", "n_gpus": [0-9]*, "steps": [0-9]*, "warmup": [0-9]*, "ms_per_step": [0-9.]*' $O/bench.log ;;
+    bench)   run bench 400 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-exact-fp32 --no-other-configs --no-live-pmc --shape-report $O/conv_shapes.txt; grep -o '"value": [0-9.]*, "unit": "images/sec", "n_gpus": [0-9]*, "steps": [0-9]*, "warmup": [0-9]*, "ms_per_step": [0-9.]*' $O/bench.log ;;
     bench_full) run bench_full 900 python bench.py --shape-report $O/conv_shapes_full.txt; tail -c 3000 $O/bench_full.log ;;
     prof)    STEPS=5 BENCH_ARGS="--no-kernel-profile --no-exact-fp32 --no-other-configs" timeout -k 5 400 bash tools/prof_bench.sh ${O#gpurun_out/}/prof < /dev/null > $O/prof.log 2>&1; echo "== prof t=$(el)"; head -50 $O/prof/alone.txt | cut -c1-140 ;;
     tests_all) run tests_all 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider --durations=15; tail -25 $O/tests_all.log ;;
