@@ -324,7 +324,8 @@ def pin_const_caches():
 
 def const_cache_put(cache, key, value):
     if not _const_pinned[0] and len(cache) >= CONST_CACHE_MAX:
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         cache.clear()
     cache[key] = value
     return value

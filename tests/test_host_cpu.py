@@ -644,3 +644,24 @@ def test_gpu_suite_order_and_perf_marker():
     perf = subprocess.run([sys.executable, "-m", "pytest", "tests", "-q", "-m", "perf", "--collect-only", "-p", "no:cacheprovider"],
                           cwd=root, capture_output=True, text=True, timeout=300).stdout
     assert "test_gpu_perf.py::test_graph_mode_host_cost" in perf
+
+
+def test_value_keyed_constant_caches_are_bounded_until_a_graph_is_captured():
+    """ops._idx_cache / networks._LossVectors grow with every distinct value (varying colleague picks, a ramped loss
+    weight).  hip.const_cache_put bounds them at CONST_CACHE_MAX entries -- until the first hipGraph capture pins them (graphs
+    hold the addresses)."""
+    import council_gan_amd as cga
+    hip = cga.hip
+    pinned = hip._const_pinned[0]
+    try:
+        hip._const_pinned[0] = False
+        cache = {}
+        for i in range(hip.CONST_CACHE_MAX + 5):
+            hip.const_cache_put(cache, i, i)
+        assert len(cache) == 5 and (hip.CONST_CACHE_MAX + 4) in cache          # cleared once, at the bound
+        hip.pin_const_caches()
+        for i in range(hip.CONST_CACHE_MAX + 5):
+            hip.const_cache_put(cache, ("p", i), i)
+        assert len(cache) == hip.CONST_CACHE_MAX + 10                            # pinned: nothing is ever dropped
+    finally:
+        hip._const_pinned[0] = pinned
