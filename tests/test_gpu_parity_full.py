@@ -109,8 +109,8 @@ def test_bench_batch_generator_gradient_statistic(cga):
 
     WHAT IS ASSERTED, AND WHAT IS NOT.  The statistic is heavy-tailed: one ReLU / focus-loss sign flip at a high-leverage pixel moves
     a member's whole gradient by 5-20 % (the reference's own fp32 arithmetic: one such draw in twelve, 6.7e-2), and which draws flip
-    is re-drawn by ANY change of the forward pass's last bits (round 6 measured 3 and then 6 excursions of 12 on this datapath after a
-    change that only made three thin layers MORE accurate).  Asserted are the stable parts: the QUIET level (lower quartile of the
+    is re-drawn by ANY change of the forward pass's last bits (round 6 measured 3, 6 and 5 excursions of 12 on this datapath over three
+    builds that only changed thin first / head layers).  Asserted are the stable parts: the QUIET level (lower quartile of the
     12 draws) <= 3 x the reference's (measured 1.8-2.0 x: 22-bit operands and a 432-long accumulation chain give 2 x the CPU kernels'
     forward round-off), every draw <= 0.3 (a single flip's size; a wrong kernel is not bounded by it), losses <= 1e-3.
     NOT met, and not asserted: the survey's "err <= 2 x the reference's" on the median / maximum of the 12 draws -- this datapath
