@@ -799,9 +799,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (FOLD > 0 && BM == 128 
     float4 av[PF][A_V4], bv[PF][B_V4];
     int ld_kt = 0, ld_tap = 0, ld_c0 = 0;  // slice the next load_tile() fetches (clamped to the last slice)
 
-    // (the chunked-sum 128 x 128 / 8-wave tile re-reads its rows' gather data from the LDS row table instead of holding it in registers:
-    // with one fragment set that brings it to 128 registers -- two blocks per CU)
-    constexpr bool ROWS_LDS = false;      // (measured: 134 registers with it, 130 without)
     auto load_tile = [&](auto set_c) {
         constexpr int SET = decltype(set_c)::value;
         const int td = __builtin_amdgcn_readfirstlane(taps[ld_tap]);
@@ -809,14 +806,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (FOLD > 0 && BM == 128 
         const unsigned cb = (unsigned)(ld_c0 + kc * 4);
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
-            int rb_ = rbase[i], ry_ = rly[i], rx_ = rlx[i];
-            if constexpr (ROWS_LDS) {
-                const RowInfo ri = rows[r0 + RPV * i];
-                rb_ = ri.base, ry_ = ri.ly0, rx_ = ri.lx0;
-            }
-            const int ly = ry_ + dy, lx = rx_ + dx;
-            const bool ok = rb_ >= 0 && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
-            const unsigned pix = (unsigned)(rb_ + (ly >> g.up) * g.W + (lx >> g.up));
+            const int ly = rly[i] + dy, lx = rlx[i] + dx;
+            const bool ok = rbase[i] >= 0 && (unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl;
+            const unsigned pix = (unsigned)(rbase[i] + (ly >> g.up) * g.W + (lx >> g.up));
             // branch-free: an invalid tap only sets the top offset bit, the range check then returns zeros
             av[SET][i] = buf_load4(xr, ((pix * (unsigned)Ct + cb) << 2) | (ok ? 0u : CG_OOB));
         }
@@ -2066,7 +2058,9 @@ static bool wgrad_thin_on() { return tune().wgrad_thin != 0; }
 static int thin_wgrad_splits(const cg_conv_geom* g, int nmember) {
     const int imgs = g->N / nmember;
     const int ntiles = imgs * ((g->Ho + 15) / 16) * ((g->Wo + 15) / 16);
-    int gx = 256 / nmember;                                     // one resident block per CU over all members
+    // one resident block per CU over all members (two -- held to 128 registers -- spill and gain nothing: 793 vs 807 us on the council
+    // discriminator's first layer, the other variants slower, gpurun_out/s20)
+    int gx = 256 / nmember;
     if (gx < 1) gx = 1;
     return gx < ntiles ? gx : ntiles;
 }

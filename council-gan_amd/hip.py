@@ -3,7 +3,6 @@
 There is NO fallback: if the shared library is missing, or a kernel is called without a GPU,
 this raises.  The product path never routes through PyTorch compute ops or the oracle."""
 import ctypes
-import threading
 import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int8, c_int32, c_int64, c_size_t, c_void_p
 

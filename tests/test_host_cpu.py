@@ -665,3 +665,29 @@ def test_value_keyed_constant_caches_are_bounded_until_a_graph_is_captured():
         assert len(cache) == hip.CONST_CACHE_MAX + 10                            # pinned: nothing is ever dropped
     finally:
         hip._const_pinned[0] = pinned
+
+
+def test_hot_kernels_use_no_scratch_and_keep_their_occupancy():
+    """Compile-time guard (no GPU): registers / scratch of the kernels the step spends its time in, read from the built library's
+    code-object metadata (tools/kernel_resources.py).  A loop left rolled by hipcc moved the 128x128 wave tile's 256 accumulators to
+    scratch in round 6 until it became a compile-time loop -- silently, but for this table."""
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("ROCm LLVM tools not installed")
+    root = os.path.join(os.path.dirname(__file__), "..")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_resources.py"), "conv_fwd_x3w_kernel", "conv_wgrad_x3tw_kernel",
+                          "conv_fwd_x3_kernel", "conv_fwd_pipe_kernel", "conv_fwd_thin_x3_kernel"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = {}
+    for line in out.stdout.splitlines()[1:]:
+        f = line.split()
+        name, (agpr, vgpr, spill, sgpr, lds, scratch, waves) = " ".join(f[:-7]), map(int, f[-7:])
+        rows[name] = dict(agpr=agpr, vgpr=vgpr, spill=spill, lds=lds, scratch=scratch, waves=waves)
+    assert len(rows) >= 40, len(rows)
+    dom = [r for n, r in rows.items() if "conv_fwd_x3w_kernel" in n and "256" in n]
+    assert dom and all(r["scratch"] == 0 for r in dom)                       # every variant of the wide tile, the 4-wave ones included
+    spilled = {n: r for n, r in rows.items() if r["scratch"] > 16}           # (the chunked 128x128 fp32 tile: 2 dwords by design)
+    assert not spilled, spilled
+    wide = [r for n, r in rows.items() if "conv_fwd_x3w_kernel" in n and "ILi256ELi256ELi128ELi64ELi1ELi0ELi0E" in n]
+    assert wide and wide[0]["waves"] >= 2 and wide[0]["lds"] <= 160 * 1024    # two waves per SIMD, one block per CU
