@@ -736,7 +736,30 @@ def test_split_precision_weight_gradient_wide_tile(cga, shape):
                      lambda lib, prev: lib.cg_conv2d_wgrad_x3_wide(prev))
 
 
-def _wgrad_tile_case(cga, shape, switch, restore):
+@pytest.mark.parametrize("shape", [(4, 16, 16, 256, 256, 3, 1, 1), (6, 8, 16, 128, 128, 3, 1, 1), (6, 9, 16, 64, 128, 4, 2, 1),
+                                   (3, 16, 16, 64, 64, 3, 1, 1)],
+                         ids=["wide_3x3_256to256", "128x128_ragged_rows", "128x128_multitap_4x4s2", "64x128_3x3_64to64"])
+def test_weight_gradient_xcd_grouped_block_order_is_bit_identical(cga, shape):
+    """cg_tuning.wgrad_xcd_group (round 6): the split-precision weight-gradient grids walk their (tile, member, split) cells in an
+    order that keeps the tap tiles of one position range on ONE XCD.  Every block computes the same cell either way: weight and
+    bias gradients must be bit-identical with the grouping on and off, for one member and for a member-batched launch, on the
+    LDS-DMA tile and on the transposing-read tiles, with row counts that are multiples of no tile edge."""
+    from council_gan_amd import hip
+
+    def switch(lib, on):
+        prev = hip.tuning().wgrad_xcd_group
+        t = hip.tuning()
+        t.wgrad_xcd_group = 1 if on else 0
+        import ctypes
+        hip.check(lib.cg_tuning_set(ctypes.byref(t)), "cg_tuning_set")
+        return prev
+
+    def restore(lib, prev):
+        switch(lib, bool(prev))
+    _wgrad_tile_case(cga, shape, switch, restore, exact=True)
+
+
+def _wgrad_tile_case(cga, shape, switch, restore, exact=False):
     from ctypes import byref
     from council_gan_amd import hip, ops
     N, H, W, Cin, Cout, K, stride, pad = shape
@@ -792,6 +815,8 @@ def _wgrad_tile_case(cga, shape, switch, restore):
                 assert rel(got[0], rw) < 2e-5 and rel(got[1], rb) < 2e-5, (n, m, rel(got[0], rw), rel(got[1], rb))
             if has_base:
                 assert rel(wide[n][m][0], base[n][m][0]) < 2e-6
+                if exact:
+                    assert torch.equal(wide[n][m][0], base[n][m][0]) and torch.equal(wide[n][m][1], base[n][m][1])
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 7, 12, 13, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 60, 64, 67, 68])
