@@ -2428,6 +2428,7 @@ static X3Epi x3_epilogue_of(const cg_x3_epilogue* epi) {
         e.act_type = epi->act_src ? epi->act_type : 0;
         e.act_src = (const _Float16*)epi->act_src;
         e.out_state = epi->l1_ctl ? epi->out_state : nullptr;
+        e.addend = epi->addend;
     }
     return e;
 }

@@ -34,7 +34,7 @@ class Group(ctypes.Structure):
 class X3Epilogue(ctypes.Structure):
     """cg_x3_epilogue: bounded-split / fused activation-backward extras of the split-precision forward and data-gradient calls."""
     _fields_ = [("l1_ctl", c_void_p), ("in_state", c_void_p), ("in_nslots", c_int32), ("act_type", c_int32),
-                ("act_src", c_void_p), ("out_state", c_void_p)]
+                ("act_src", c_void_p), ("out_state", c_void_p), ("addend", c_void_p)]
 
 
 class Tuning(ctypes.Structure):

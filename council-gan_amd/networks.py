@@ -39,15 +39,16 @@ class AdaptiveInstanceNorm2d(nn.Module):
         self.weight = None
         self.bias = None
         self.params = None      # [B, P] MLP output
+        self.pgrad = None       # ops.ParamGrad of that matrix (shared by the AdaIN layers of one decoder pass) or None
         self.goff = self.boff = 0
         # dummy buffers, kept for state_dict compatibility (networks.py:636-638)
         self.register_buffer('running_mean', torch.zeros(num_features))
         self.register_buffer('running_var', torch.ones(num_features))
 
-    def forward(self, x, act='none', residual=None, stats=None, want_split=False, want_f32=True):
+    def forward(self, x, act='none', residual=None, stats=None, want_split=False, want_f32=True, skip=None):
         assert self.params is not None, "Please assign weight and bias before calling AdaIN!"
         return ops.adain(x, self.params, self.goff, self.boff, act=act, residual=residual, eps=self.eps, stats=stats,
-                         want_split=want_split, want_f32=want_f32)
+                         want_split=want_split, want_f32=want_f32, skip=skip, pgrad=self.pgrad)
 
     def __repr__(self):
         return self.__class__.__name__ + '(' + str(self.num_features) + ')'
@@ -105,7 +106,9 @@ class Conv2dBlock(nn.Module):
         self.activation_type = activation
         self.conv = nn.Conv2d(input_dim, output_dim, kernel_size, stride, bias=self.use_bias)
 
-    def forward(self, x, x2=None, upsample=False, residual=None, want_f32=True):
+    def forward(self, x, x2=None, upsample=False, residual=None, want_f32=True, skip=None):
+        # skip (ops.SkipLink, ResBlock only): the block's second layer (residual given) hands the skip edge's gradient over in
+        # its norm's backward, the first layer (no residual) adds it to its convolution's data gradient
         # want_f32=False: the caller knows that the only consumer of this block's output is a convolution that reads the
         # {hi, lo} planes the norm emits -- the fp32 copy is then not written (split-precision datapath only)
         act = self.activation_type
@@ -117,12 +120,12 @@ class Conv2dBlock(nn.Module):
         want_split = wmgr is not None and self.conv.out_channels % 32 == 0
         y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, fused_act, x2=x2,
                        upsample=upsample, stats=stats, wmgr=wmgr, want_split=want_split,
-                       want_f32=want_f32 or self.norm is not None)
+                       want_f32=want_f32 or self.norm is not None, skip=skip if residual is None else None)
         if self.norm_type == 'in':
             y = ops.instance_norm(y, act=act, residual=residual, eps=self.norm.eps, stats=stats, want_split=want_split,
-                                  want_f32=want_f32)
+                                  want_f32=want_f32, skip=skip)
         elif self.norm_type == 'adain':
-            y = self.norm(y, act=act, residual=residual, stats=stats, want_split=want_split, want_f32=want_f32)
+            y = self.norm(y, act=act, residual=residual, stats=stats, want_split=want_split, want_f32=want_f32, skip=skip)
         elif self.norm_type == 'ln':
             y = ops.activation(self.norm(y), act)
             if residual is not None:
@@ -172,7 +175,10 @@ class ResBlock(nn.Module):
         self.model = nn.Sequential(*model)
 
     def forward(self, x):
-        return self.model[1](self.model[0](x, want_f32=False), residual=x)
+        # the skip edge's gradient joins the first convolution's data gradient (ops.SkipLink) when both layers have a norm whose
+        # backward can hand it over; otherwise the autograd engine adds the two gradients of x as usual
+        link = ops.skip_link(x) if self.model[1].norm_type in ('in', 'adain') else None
+        return self.model[1](self.model[0](x, want_f32=False, skip=link), residual=x, skip=link)
 
 
 class LinearBlock(nn.Module):
@@ -436,9 +442,12 @@ class AdaINGen(nn.Module):
         if mods is None or mods[0] is not model:
             mods = (model, [m for m in model.modules() if m.__class__.__name__ == "AdaptiveInstanceNorm2d"])
             self.__dict__['_adain_mods'] = mods
+        # one gradient buffer for the whole matrix instead of a full-size gradient per layer added up by the engine (ops.ParamGrad)
+        adain_params, pgrad = ops.adain_param_fork(adain_params)
         for m in mods[1]:
             d = m.__dict__                     # plain attributes: skip nn.Module.__setattr__'s type dispatch
             d['params'] = adain_params
+            d['pgrad'] = pgrad
             d['bias'] = adain_params[:, m.boff:m.boff + m.num_features]        # views, no copy
             d['weight'] = adain_params[:, m.goff:m.goff + m.num_features]
 

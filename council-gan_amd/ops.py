@@ -168,7 +168,7 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, weight, bias, wgrad_buf, bgrad_buf, stride, pad, act, up, stats, xsplit=None, wsplit=None,
                 out_split=None, amax_out=None, wmgr=None, wref=None, dz_split_ok=None, x_no_f32=False, bounded=None, x_bwd=None,
-                bwd_want=None, want_f32=True):
+                bwd_want=None, want_f32=True, skip=None):
         # wref = (cg_group or None, the Parameter object): resolved by the caller, where the tensor still carries its
         # Python attributes
         lib = _lib()
@@ -248,6 +248,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.x_no_f32 = bool(x_no_f32)
         ctx.x_bwd = x_bwd        # what the producer of x wants from this layer's data gradient (see backward)
         ctx.bwd_cell = None
+        ctx.skip = skip          # SkipLink: the gradient of the ResBlock's skip connection joins this layer's data gradient
         ctx.g, ctx.meta = g, (KH, KW, stride, pad, act, int(up), bias is not None)
         ctx.wgrad_buf, ctx.bgrad_buf = wgrad_buf, bgrad_buf
         ctx.grp, ctx.weight, ctx.wmgr, ctx.nm = grp, wparam, wmgr, _G.n      # backward may run outside the members() scope
@@ -340,12 +341,17 @@ class _Conv2d(torch.autograd.Function):
         if pre is not None and act and not applied:
             raise hip.HipError("a gradient delivered in split form only reached a layer with a fused activation")
         # data gradients: split-precision kernel when the layer qualifies (dz gets a device-side power-of-two scale)
+        addend = ctx.skip.take() if ctx.skip is not None else None
+        if addend is not None and (x2 is not None or not ctx.needs_input_grad[0]):
+            raise hip.HipError("a skip-connection gradient was handed to a layer that has no single input gradient to add it to")
+
         def dgrad(ci0, nci):
             if x3_dgrad:
-                fuse = ctx.x_bwd if (ci0 == 0 and nci == x.shape[1] and x2 is None and not up) else None
+                fuse = ctx.x_bwd if (ci0 == 0 and nci == x.shape[1] and x2 is None and not up and addend is None) else None
                 return conv_dgrad_x3(g, dzs, w, ci0, nci, grp=grp, weight=ctx.weight, wmgr=ctx.wmgr, nm=ctx.nm,
-                                     fuse=fuse, xsplit=ctx.xsplit)
-            return conv_dgrad(g, dz, w, ci0, nci, grp=grp)
+                                     fuse=fuse, xsplit=ctx.xsplit, addend=addend)
+            d = conv_dgrad(g, dz, w, ci0, nci, grp=grp)
+            return d if addend is None else add(d, addend)
 
         def run_dgrads():
             d1 = dgrad(0, x.shape[1]) if ctx.needs_input_grad[0] else None
@@ -399,7 +405,7 @@ class _Conv2d(torch.autograd.Function):
                         t.record_stream(side)
         if not (side is not None and WGRAD_AFTER_DGRAD):
             dx, dx2 = run_dgrads()
-        return (dx, dx2, dw, db) + (None,) * 19
+        return (dx, dx2, dw, db) + (None,) * 20
 
 
 # Weight gradients leave the chain of dependent backward kernels: nothing downstream of a layer's backward needs its dW
@@ -590,7 +596,7 @@ X3_DYNAMIC_INPUT = True
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=False, stats=None, wmgr=None,
-           want_split=False, want_f32=True):
+           want_split=False, want_f32=True, skip=None):
     """Functional conv.  `weight` may be an nn.Parameter managed by a flat optimizer buffer.  `stats`: an empty
     list when an instance norm consumes the output next -- the conv appends (partials, rows) if its epilogue
     produced the norm's partial sums (pass the same list to instance_norm / adain).
@@ -645,7 +651,7 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act="none", x2=None, upsample=
     y = _Conv2d.apply(x, x2, weight, bias, getattr(weight, "_cg_grad", None),
                       getattr(bias, "_cg_grad", None) if bias is not None else None,
                       int(stride), int(pad), ACT[act], bool(upsample), stats, xsplit, wsplit, out_split, amax_out, wmgr,
-                      (_grp(weight), weight), dz_ok, no_f32, bounded, getattr(x, "_cg_bwd", None), bwd_want, bool(want_f32))
+                      (_grp(weight), weight), dz_ok, no_f32, bounded, getattr(x, "_cg_bwd", None), bwd_want, bool(want_f32), skip)
     if dz_ok:
         y._cg_dz_split_ok = True
     if bwd_want:
@@ -758,9 +764,11 @@ class _InstNormAct(torch.autograd.Function):
     of `params` ([N, P], the MLP output, networks.py:303-312) or absent (plain nn.InstanceNorm2d)."""
 
     @staticmethod
-    def forward(ctx, x, params, goff, boff, residual, act, eps, stats, out_split=None, dx_split_only=False, no_f32=False):
+    def forward(ctx, x, params, goff, boff, residual, act, eps, stats, out_split=None, dx_split_only=False, no_f32=False,
+                skip=None, pgrad=None):
         lib = _lib()
         ctx.dx_split_only = bool(dx_split_only)
+        ctx.pgrad = pgrad if params is not None else None      # ParamGrad: the shared gradient buffer of the AdaIN parameter matrix
         x, residual = nhwc(x), nhwc(residual)
         N, C, H, W = x.shape
         HW = H * W
@@ -796,6 +804,7 @@ class _InstNormAct(torch.autograd.Function):
                                         stream()), "cg_instnorm_apply")
         ctx.save_for_backward(x, mean, rstd, params)
         ctx.meta = (goff, boff, act, residual is not None)
+        ctx.skip = skip if residual is not None else None
         return y
 
     @staticmethod
@@ -811,7 +820,12 @@ class _InstNormAct(torch.autograd.Function):
         dparams = None
         if params is not None:
             gp, bp, gs = _off(params, goff), _off(params, boff), params.shape[1]
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[1] and ctx.pgrad is not None:
+                # this layer's 2C columns go straight into the buffer all AdaIN layers of the decoder share; the fork node
+                # (adain_param_fork) reports it as the matrix's gradient once, after the last of them
+                shared = ctx.pgrad.buffer(params)
+                dgp, dbp = _off(shared, goff), _off(shared, boff)
+            elif ctx.needs_input_grad[1]:
                 dparams = torch.empty_like(params)
                 check(lib.cg_fill(ptr(dparams), dparams.numel(), 0.0, stream()), "cg_fill")
                 dgp, dbp = _off(dparams, goff), _off(dparams, boff)
@@ -839,7 +853,13 @@ class _InstNormAct(torch.autograd.Function):
                                       ptr(ws), ws.numel(), ptr(state), byref(nslots), stream()), "cg_instnorm_bwd")
             if nslots.value:
                 dx._cg_amax = (state, nslots.value, dx._version)     # the conv before this norm splits dx without measuring it again
-        return dx, dparams, None, None, (dy if has_res else None), None, None, None, None, None, None
+        dres = dy if has_res else None
+        if dres is not None and ctx.skip is not None:
+            # the first convolution of the block adds it to its data gradient in that kernel's epilogue (SkipLink): autograd sees
+            # no gradient on the skip edge and the sum arrives on the convolution's edge
+            ctx.skip.give(dres)
+            dres = None
+        return dx, dparams, None, None, dres, None, None, None, None, None, None, None, None
 
 
 # CG_DX_SPLIT=0: instance-norm backward always writes fp32 dx and the convolution splits it in a pass of its own (A/B switch)
@@ -850,11 +870,11 @@ DX_SPLIT = os.environ.get("CG_DX_SPLIT", "1") != "0"
 NORM_NO_F32 = os.environ.get("CG_NORM_NO_F32", "1") != "0"
 
 
-def _norm_apply(x, params, goff, boff, residual, act, eps, stats, want_split, want_f32=True):
+def _norm_apply(x, params, goff, boff, residual, act, eps, stats, want_split, want_f32=True, skip=None, pgrad=None):
     out_split = [] if (want_split and X3_FORWARD) else None
     y = _InstNormAct.apply(x, params, goff, boff, residual, ACT[act], float(eps), stats, out_split,
                            bool(getattr(x, "_cg_dz_split_ok", False)),
-                           bool(out_split is not None and not want_f32 and NORM_NO_F32 and X3_BACKWARD))
+                           bool(out_split is not None and not want_f32 and NORM_NO_F32 and X3_BACKWARD), skip, pgrad)
     if out_split:
         y._cg_split = out_split[0]
         if len(out_split) > 1:
@@ -862,12 +882,103 @@ def _norm_apply(x, params, goff, boff, residual, act, eps, stats, want_split, wa
     return y
 
 
-def instance_norm(x, act="none", residual=None, eps=1e-5, stats=None, want_split=False, want_f32=True):
-    return _norm_apply(x, None, 0, 0, residual, act, eps, stats, want_split, want_f32)
+def instance_norm(x, act="none", residual=None, eps=1e-5, stats=None, want_split=False, want_f32=True, skip=None):
+    return _norm_apply(x, None, 0, 0, residual, act, eps, stats, want_split, want_f32, skip)
 
 
-def adain(x, params, goff, boff, act="none", residual=None, eps=1e-5, stats=None, want_split=False, want_f32=True):
-    return _norm_apply(x, params, int(goff), int(boff), residual, act, eps, stats, want_split, want_f32)
+def adain(x, params, goff, boff, act="none", residual=None, eps=1e-5, stats=None, want_split=False, want_f32=True, skip=None,
+          pgrad=None):
+    return _norm_apply(x, params, int(goff), int(boff), residual, act, eps, stats, want_split, want_f32, skip, pgrad)
+
+
+# CG_ADAIN_FORK=0: every AdaIN layer returns a full-size gradient of the parameter matrix and the autograd engine adds them
+ADAIN_FORK = os.environ.get("CG_ADAIN_FORK", "1") != "0"
+
+
+class ParamGrad:
+    """Gradient of the AdaIN parameter matrix ([N, P], the MLP output; networks.py:303-312 hands column slices of it to the
+    decoder's AdaIN layers) while a backward pass is collecting it.  The layers own DISJOINT columns, so instead of one zero-filled
+    [N, P] gradient per layer plus the engine's additions, every layer's backward writes its columns into one shared buffer
+    (`buffer`), and the fork node between the MLP and the layers (`adain_param_fork`) -- which the engine runs after the last of
+    them -- reports it (`take`)."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+    def buffer(self, like):
+        if self.buf is None:
+            self.buf = torch.empty_like(like)
+            check(_lib().cg_fill(ptr(self.buf), self.buf.numel(), 0.0, stream()), "cg_fill")
+        return self.buf
+
+    def take(self):
+        b, self.buf = self.buf, None
+        return b
+
+
+class _ParamFork(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, pgrad):
+        ctx.pgrad = pgrad
+        ctx.set_materialize_grads(False)
+        return params.view_as(params)
+
+    @staticmethod
+    def backward(ctx, g):
+        b = ctx.pgrad.take()
+        if g is not None:        # somebody differentiated through the matrix outside the AdaIN layers (m.weight / m.bias views)
+            g = g.contiguous()
+            b = g if b is None else add(b, g)
+        return b, None
+
+
+def adain_param_fork(params):
+    """(params', ParamGrad) for a parameter matrix that needs its gradient, (params, None) otherwise."""
+    if not (ADAIN_FORK and torch.is_grad_enabled() and params.requires_grad):
+        return params, None
+    pg = ParamGrad()
+    return _ParamFork.apply(params.contiguous(), pg), pg
+
+
+# CG_SKIP_FUSE=0: the gradient of a ResBlock's skip connection is accumulated by the autograd engine (an ATen add per block)
+SKIP_FUSE = os.environ.get("CG_SKIP_FUSE", "1") != "0"
+
+
+class SkipLink:
+    """One ResBlock's skip edge in the backward pass (networks.py:448-461, `out += residual`).  The block's input x has two
+    consumers -- the first convolution and the residual add fused into the second norm -- so the autograd engine would add their
+    two gradients in a pass of its own.  Instead the norm's backward hands the skip gradient over here (`give`) and reports
+    None on the skip edge; the first convolution's backward, which by construction runs later, takes it (`take`) and adds it to
+    its data gradient in the kernel's epilogue (cg_x3_epilogue.addend) -- or with cg_add where that kernel is not the
+    split-precision one.  Same values, same rounding as the engine's addition."""
+    __slots__ = ("grad",)
+
+    def __init__(self):
+        self.grad = None
+
+    def give(self, g):
+        if self.grad is not None:
+            raise hip.HipError("skip link: a gradient was handed over twice before the convolution took it")
+        self.grad = g
+
+    def take(self):
+        g, self.grad = self.grad, None
+        return g
+
+
+def skip_link(x):
+    """A SkipLink for a block whose input is x, or None when no gradient flows to x (or the fusion is switched off)."""
+    return SkipLink() if (SKIP_FUSE and torch.is_grad_enabled() and x.requires_grad) else None
+
+
+def add(a, b):
+    """a + b (fp32, same shape and layout) on the library's own kernel; no autograd."""
+    if a.shape != b.shape or a.stride() != b.stride() or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise hip.HipError("add: operands differ in shape / layout / dtype")
+    out = torch.empty_like(a)
+    check(_lib().cg_add(ptr(a), ptr(b), ptr(out), a.numel(), stream()), "cg_add")
+    return out
 
 
 class _Activation(torch.autograd.Function):
@@ -1205,7 +1316,7 @@ def act_bwd_split(dy, y, act, want_fp32, amax=None):
     return dz, SplitTensor(buf, dy.shape, state=state)
 
 
-def conv_dgrad_x3(g, dz, w, ci0, nci, grp=None, weight=None, wmgr=None, nm=1, fuse=None, xsplit=None):
+def conv_dgrad_x3(g, dz, w, ci0, nci, grp=None, weight=None, wmgr=None, nm=1, fuse=None, xsplit=None, addend=None):
     """conv_dgrad on the split-precision kernel: dz is split with its device-side scale; needs Cout % 32 == 0.  The weights
     are re-laid-out and split per launch into the workspace -- or, for a parameter of a SplitWeights-managed optimizer
     (`weight`, `wmgr`), once per weight version (SplitWeights.dgrad_weights)."""
@@ -1245,9 +1356,19 @@ def conv_dgrad_x3(g, dz, w, ci0, nci, grp=None, weight=None, wmgr=None, nm=1, fu
         # the kernel leaves the per-block maxima of dx behind: the layer below splits its dz without measuring it again
         state = torch.empty(hip.SPLIT_STATE_FLOATS, dtype=torch.float32, device=dxl.device) if not up else None
         nslots = ctypes.c_int(0)
-        check(lib.cg_conv2d_dgrad_x3_run(byref(g), grp, dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), ptr(wt), 1.0, wmgr.scale_ptr(),
-                                         ci0, nci, ptr(dxl), ptr(state), byref(nslots) if state is not None else None, stream()),
-              "cg_conv2d_dgrad_x3_run")
+        if addend is not None and not up and x3_interleaved():
+            # the skip connection's gradient joins dx in the kernel's epilogue (cg_x3_epilogue.addend): no pass of its own
+            if tuple(addend.shape) != tuple(dxl.shape) or addend.stride() != dxl.stride() or addend.dtype != torch.float32:
+                raise hip.HipError("skip-connection gradient: shape / layout differs from the data gradient it joins")
+            epi = hip.X3Epilogue(None, None, 0, 0, None, None, addend.data_ptr())
+            check(lib.cg_conv2d_dgrad_x3_run_e(byref(g), grp, dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), ptr(wt), 1.0, wmgr.scale_ptr(),
+                                               ci0, nci, ptr(dxl), None, 0, byref(epi), ptr(state), byref(nslots), stream()),
+                  "cg_conv2d_dgrad_x3_run_e")
+            addend = None
+        else:
+            check(lib.cg_conv2d_dgrad_x3_run(byref(g), grp, dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), ptr(wt), 1.0, wmgr.scale_ptr(),
+                                             ci0, nci, ptr(dxl), ptr(state), byref(nslots) if state is not None else None, stream()),
+                  "cg_conv2d_dgrad_x3_run")
         if nslots.value:
             dxl._cg_amax = (state, nslots.value, dxl._version)
     else:
@@ -1257,10 +1378,10 @@ def conv_dgrad_x3(g, dz, w, ci0, nci, grp=None, weight=None, wmgr=None, nm=1, fu
         check(lib.cg_conv2d_dgrad_x3(byref(g), dzs.hi_ptr(), dzs.lo, dzs.scale_ptr(), ptr(w), ci0, nci, ptr(dxl), ptr(ws),
                                      ws.numel(), stream()), "cg_conv2d_dgrad_x3")
     if not up:
-        return dxl
+        return dxl if addend is None else add(dxl, addend)
     dx = empty_nhwc(N, nci, H, W, dxl)
     check(lib.cg_upsample2x_bwd(ptr(dxl), ptr(dx), N, H, W, nci, stream()), "cg_upsample2x_bwd")
-    return dx
+    return dx if addend is None else add(dx, addend)
 
 
 def conv2d_x3(xs, wsplit, Cout, KH, KW, bias=None, stride=1, pad=0, act="none", upsample=False, stats=None, grp=None):
@@ -1520,10 +1641,13 @@ class _FocusLoss(torch.autograd.Function):
         out = out.view(nm, 4)
         total, parts = (out[:, 0], out[:, 1:]) if nm > 1 else (out[0, 0], out[0, 1:])
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)      # no zero-filled gradient for `parts` (an ATen fill per backward)
         return total, parts
 
     @staticmethod
     def backward(ctx, g, _gparts):
+        if g is None:
+            return (None,) * 10
         lib = _lib()
         mask, sums = ctx.saved_tensors
         center, eps, w_zo, w_total, w_tv, use_abs, use_square, nm = ctx.meta

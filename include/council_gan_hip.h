@@ -230,7 +230,12 @@ int cg_colsum_split(const cg_group* group, const void* z_split, size_t lo_elems,
  *   act_src    hi plane ({hi, lo} form, same geometry as the output) of the tensor the output is the gradient OF; the output is
  *              multiplied by act'(act_src), act_type = CG_ACT_RELU / CG_ACT_LRELU (sign-only derivatives): the activation
  *              backward of the layer below, fused into the data-gradient epilogue (trainer_council.py:779,882 loss.backward())
- *   out_state  CG_SPLIT_STATE_FLOATS floats: [0] = the bound, [1] = the scale of the planes, [2 ..] = block maxima of the outputs */
+ *   out_state  CG_SPLIT_STATE_FLOATS floats: [0] = the bound, [1] = the scale of the planes, [2 ..] = block maxima of the outputs
+ *   addend     fp32 tensor of the output's own geometry (NHWC) added to every output value after bias / activation factor, or
+ *              NULL: the gradient that reaches a ResBlock's input through its skip connection (`out += residual`,
+ *              networks.py:459-460) joins the data gradient of the block's first convolution in that kernel's epilogue instead
+ *              of in a pass of its own; bit for bit the separate fp32 addition (the value is rounded to fp32 first).  Block
+ *              maxima / planes / statistics are those of the SUM. */
 typedef struct cg_x3_epilogue {
     const float* l1_ctl;
     const float* in_state;
@@ -238,6 +243,7 @@ typedef struct cg_x3_epilogue {
     int32_t act_type;
     const void* act_src;
     float* out_state;
+    const float* addend;
 } cg_x3_epilogue;
 size_t cg_weight_l1_workspace(int Cin, int nmember);      /* for by_input_channel = 1 (deterministic two-stage column sums) */
 int cg_weight_l1_bound(const cg_group* group, const float* w, int Cout, int T, int Cin, const float* bias, int by_input_channel,

@@ -1172,6 +1172,88 @@ def test_activation_backward_takes_its_scale_from_the_data_gradient_kernel(cga, 
                 assert rel(a, b) < 2e-5, (on, m)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 16, 16, 'in', False), (4, 256, 32, 32, 'in', False), (16, 256, 64, 64, 'in', False),
+                                  (2, 96, 12, 20, 'in', False), (2, 64, 16, 16, 'in', True), (16, 256, 64, 64, 'in', True),
+                                  (2, 64, 16, 16, 'none', False)])
+def test_resblock_skip_gradient_joins_the_data_gradient_epilogue(cga, case, monkeypatch):
+    """networks.py:448-461 (`out += residual`): the block input's two gradients -- through the first convolution and through the
+    skip edge -- are added in the data-gradient kernel's epilogue (ops.SkipLink, cg_x3_epilogue.addend) instead of by the autograd
+    engine.  Two stacked blocks, so the upper block's fused sum is the lower block's incoming gradient.  The sum is formed after
+    the value is rounded to fp32: every gradient BIT-IDENTICAL to the engine's addition (CG_SKIP_FUSE=0) -- on the wide LDS-DMA
+    tile (the benchmark's member-batched launch: 256 channels at 64x64, batch 16), the register-staged tiles, ragged rows, the
+    generic epilogue copies, and (norm 'none': no hand-over point) with the link declined.  Small cases also against fp64."""
+    from council_gan_amd import ops, optim, networks, hip
+    N, C, H, W, norm, generic = case
+    torch.manual_seed(5)
+    # the benchmark-size cases keep the model's ReLU; the cases that are also compared with fp64 take a smooth activation (a ReLU
+    # whose pre-activation sits within round-off of zero flips, and the comparison then measures that lottery, not the kernels)
+    activation = 'relu' if N * H * W >= 65536 else 'tanh'
+    blocks = [networks.ResBlock(C, norm=norm, activation=activation, pad_type='zero') for _ in range(2)]
+    opt = cga.FlatAdam([p for b in blocks for p in b.parameters()], lr=1e-4)
+    pool = optim.ParamPool([opt])
+    pool.materialize('cuda')
+    mgr = ops.SplitWeights(pool)
+    pool.split = mgr
+    for b in blocks:
+        for m in b.model:
+            m._cg_wmgr = mgr
+    x = torch.randn(N, C, H, W, dtype=torch.float64)
+    gy = torch.randn(N, C, H, W, dtype=torch.float64)
+    links = []
+    orig = ops.skip_link
+    monkeypatch.setattr(ops, "skip_link", lambda t: (links.append(orig(t)), links[-1])[1])
+    fused = []
+    orig_dgrad = ops.conv_dgrad_x3
+    monkeypatch.setattr(ops, "conv_dgrad_x3", lambda *a, **k: (fused.append(k.get("addend") is not None), orig_dgrad(*a, **k))[1])
+
+    def run(on):
+        monkeypatch.setattr(ops, "SKIP_FUSE", on)
+        links.clear()
+        fused.clear()
+        pool.zero_grad()
+        xd = cl(dev(x)).requires_grad_(True)
+        h = xd
+        for b in blocks:
+            h = b(h)
+        h.backward(cl(dev(gy)))
+        torch.cuda.synchronize()
+        return xd.grad.clone(), [p._cg_grad.clone() for b in blocks for p in b.parameters()], h.detach().clone()
+
+    with hip.tuned(x3_generic_epilogue=1 if generic else 0):
+        gx1, gw1, y1 = run(True)
+        n_links = sum(l is not None for l in links)
+        n_fused = fused.count(True)
+        gx0, gw0, y0 = run(False)
+    if norm == 'none':
+        assert n_links == 0 and n_fused == 0      # no norm backward to hand the gradient over: the engine adds it
+    else:
+        # the lower block's input is a leaf that wants its gradient, the upper block's is the lower block's output
+        assert n_links == 2 and all(l.grad is None for l in links if l is not None)
+        assert n_fused == 2 or C == 96, fused       # (96 channels: whichever kernel the width gets -- the result is what counts)
+    assert torch.equal(y1, y0)
+    assert torch.equal(gx1, gx0), float((gx1 - gx0).abs().max())
+    for a, b in zip(gw1, gw0):
+        assert torch.equal(a, b)
+    if N * H * W >= 65536:
+        return
+    # fp64 reference of the same two blocks
+    xr = x.clone().requires_grad_(True)
+    h = xr
+    for b in blocks:
+        r = h
+        for i, m in enumerate(b.model):
+            w, bb = m.conv.weight.detach().double().cpu(), m.conv.bias.detach().double().cpu()
+            h = F.conv2d(F.pad(h, (1, 1, 1, 1)), w, bb)
+            if norm == 'in':
+                h = F.instance_norm(h, eps=1e-5)
+            if i == 0:
+                h = torch.tanh(h)
+        h = h + r
+    h.backward(gy)
+    assert rel(y1.double().cpu(), h.detach()) < 2e-5
+    assert rel(gx1.double().cpu(), xr.grad) < 5e-5, rel(gx1.double().cpu(), xr.grad)
+
+
 @pytest.mark.parametrize("members", [1, 2])
 def test_fused_decoder_head_matches_layer_by_layer(cga, members):
     """cg_decoder_head_fwd_x3: the decoder's three 1x1 convolutions + mask / blend head (networks.py:393-407) as one kernel,

@@ -48,6 +48,7 @@ done ;;
     prof)    STEPS=5 BENCH_ARGS="--no-kernel-profile --no-exact-fp32 --no-other-configs" timeout -k 5 400 bash tools/prof_bench.sh ${O#gpurun_out/}/prof < /dev/null > $O/prof.log 2>&1; echo "== prof t=$(el)"; head -50 $O/prof/alone.txt | cut -c1-140 ;;
     tests_all) run tests_all 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider --durations=15; tail -25 $O/tests_all.log ;;
     stat)    run stat 600 python -m pytest tests/test_gpu_parity_full.py -q -s -p no:cacheprovider -k generator_gradient_statistic; grep -A16 "generator-gradient l2-rel\|quiet level" $O/stat.log | cut -c1-200; tail -3 $O/stat.log ;;
+    skip)    run skip_test 300 python -m pytest tests/test_gpu_ops.py -q -x -p no:cacheprovider -k "resblock_skip or instance_norm or focus"; tail -3 $O/skip_test.log; bash tools/ab_step.sh ${O#gpurun_out/}/abskip "new" "engine_adds:CG_SKIP_FUSE=0 CG_ADAIN_FORK=0" 2>&1 | tee $O/abskip.log; run aten 300 python tools/aten_rows.py; grep -v Warning $O/aten.log | tail -60 | cut -c1-200 ;;
     one_member) run one_member 400 python tools/one_member_rank.py; tail -20 $O/one_member.log | cut -c1-200 ;;
     py:*)    a=${st#py:}; run py_$(echo $a | tr -c 'A-Za-z0-9' '_' | cut -c1-40) 400 python ${a//,/ } ;;
     *) echo "unknown stage $st" ;;
